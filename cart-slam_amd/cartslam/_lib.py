@@ -1,0 +1,68 @@
+"""ctypes binding of the C ABI declared in include/cart_engine.h.
+
+The shared library is built in-tree by `make -C cart-slam_amd` (or __graft_entry__.build()).
+There is NO fallback: if the library is missing, loading raises and every op fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "build", "libcart_engine.so")
+
+
+class EngineParams(C.Structure):
+    # mirrors cart_engine_params (include/cart_engine.h)
+    _fields_ = [(n, C.c_int) for n in (
+        "device_id", "width", "height", "min_disparity", "num_disparities", "paths", "p1", "p2",
+        "uniqueness_ratio", "smoothing_radius", "smoothing_iterations", "max_inflight")]
+
+
+class PlaneParams(C.Structure):
+    # mirrors cart_plane_params (include/cart_engine.h; reference include/modules/planeseg.hpp:25-34)
+    _fields_ = [(n, C.c_int) for n in (
+        "horizontal_min", "horizontal_max", "vertical_min", "vertical_max",
+        "horizontal_center", "vertical_center")]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+# every symbol include/cart_engine.h declares, with its prototype
+_vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
+PROTOTYPES = {
+    "cart_engine_default_params": (None, [C.POINTER(EngineParams)]),
+    "cart_engine_create": (_i, [C.POINTER(EngineParams), C.POINTER(_vp)]),
+    "cart_engine_destroy": (None, [_vp]),
+    "cart_last_error": (C.c_char_p, [_vp]),
+    "cart_compute_disparity": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
+    "cart_compute_disparity_batch": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp]),
+    "cart_interpolate": (_i, [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _i, _vp]),
+    "cart_disparity_derivative": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
+    "cart_plane_derivative_hist": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "cart_plane_classify": (_i, [_vp, _i, _vp, _sz, _sz, C.POINTER(PlaneParams), _i, _vp, _sz, _sz, _vp]),
+    "cart_plane_ccl": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
+    "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
+    "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
+    "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),
+    "cart_engine_set_timing": (_i, [_vp, _i]),
+    "cart_engine_last_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
+    "cart_engine_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libcart_engine.so once; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP engine is not built (run `make -C cart-slam_amd` or "
+                "__graft_entry__.build()). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib

@@ -1,0 +1,205 @@
+"""Thin Python driver over the C ABI (include/cart_engine.h).
+
+torch is used only for device memory and streams; every op below is one C-ABI call on the
+current torch stream.  Tensors are [n, h, w(, c)] or [h, w(, c)] CUDA tensors with a contiguous
+innermost row; row and frame pitches are taken from the strides (like cv::cuda::GpuMat::step).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineParams, PlaneParams
+
+INVALID = -32768  # CARTSLAM_DISPARITY_INVALID, reference include/modules/disparity.hpp:17
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _geom(t, inner):
+    """-> (n_frames, data_ptr, step_bytes, frame_stride_bytes); `inner` = trailing dims that form a row."""
+    if not t.is_cuda:
+        raise EngineError("tensor must live on the GPU")
+    batched = t.dim() == inner + 2
+    if t.dim() not in (inner + 1, inner + 2):
+        raise EngineError(f"expected {inner + 1} or {inner + 2} dims, got {t.dim()}")
+    row_dims = t.shape[-inner:]
+    exp = 1
+    for k in range(inner):
+        if t.stride(-1 - k) != exp:
+            raise EngineError("innermost row must be contiguous")
+        exp *= row_dims[-1 - k]
+    es = t.element_size()
+    step = t.stride(-inner - 1) * es
+    n = t.shape[0] if batched else 1
+    fs = t.stride(0) * es if batched else 0
+    return n, C.c_void_p(t.data_ptr()), step, fs
+
+
+class Engine:
+    """One engine = one (width, height, D, paths, ...) configuration on one GPU."""
+
+    def __init__(self, width, height, num_disparities=256, paths=4, min_disparity=4, p1=10, p2=120,
+                 uniqueness_ratio=12, smoothing_radius=-1, smoothing_iterations=5, max_inflight=12, device_id=0):
+        self._lib = _lib.load()
+        p = EngineParams()
+        self._lib.cart_engine_default_params(C.byref(p))
+        p.device_id, p.width, p.height = device_id, width, height
+        p.min_disparity, p.num_disparities, p.paths, p.p1, p.p2 = min_disparity, num_disparities, paths, p1, p2
+        p.uniqueness_ratio, p.smoothing_radius, p.smoothing_iterations = uniqueness_ratio, smoothing_radius, smoothing_iterations
+        p.max_inflight = max_inflight
+        self.params = p
+        self._h = C.c_void_p()
+        if self._lib.cart_engine_create(C.byref(p), C.byref(self._h)) != 0:
+            raise EngineError("cart_engine_create: " + self._lib.cart_last_error(None).decode())
+        self.width, self.height, self.D, self.P = width, height, num_disparities, paths
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.cart_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what}: " + self._lib.cart_last_error(self._h).decode())
+
+    # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
+    def compute_disparity(self, left, right, out=None):
+        import torch
+        ch = 3 if (left.dim() >= 3 and left.shape[-1] == 3 and left.shape[-2] == self.width
+                   and left.shape[-3] == self.height) else 1
+        inner = 2 if ch == 3 else 1
+        n, lp, ls, lfs = _geom(left, inner)
+        n2, rp, rs, rfs = _geom(right, inner)
+        if n != n2 or left.dtype != torch.uint8 or right.dtype != torch.uint8:
+            raise EngineError("left/right must be uint8 tensors of the same batch size")
+        shape = (n, self.height, self.width) if left.dim() == inner + 2 else (self.height, self.width)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.int16, device=left.device)
+        _, op, os_, ofs = _geom(out, 1)
+        self._check(self._lib.cart_compute_disparity_batch(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs,
+                                                           _stream_ptr()), "cart_compute_disparity_batch")
+        return out
+
+    def interpolate(self, disp, radius, iterations, min_disp16, max_disp):
+        n, p, s, fs = _geom(disp, 1)
+        self._check(self._lib.cart_interpolate(self._h, n, p, s, fs, radius, iterations, min_disp16, max_disp,
+                                               _stream_ptr()), "cart_interpolate")
+        return disp
+
+    # ---- derivative module (reference src/modules/disparity/derivative.cu:151-184) ----
+    def disparity_derivative(self, disp):
+        import torch
+        n, p, s, fs = _geom(disp, 1)
+        out = torch.empty(tuple(disp.shape) + (2,), dtype=torch.int16, device=disp.device)
+        hist = torch.empty((n, 256, 2), dtype=torch.int32, device=disp.device)
+        _, op, os_, ofs = _geom(out, 2)
+        self._check(self._lib.cart_disparity_derivative(self._h, n, p, s, fs, op, os_, ofs, C.c_void_p(hist.data_ptr()),
+                                                        _stream_ptr()), "cart_disparity_derivative")
+        return out, (hist if disp.dim() == 3 else hist[0])
+
+    # ---- plane label module (reference src/modules/planeseg/planeseg.cu:246-377) ----
+    def plane_derivative_hist(self, disp, hist, per_frame_hist=False):
+        """hist: int32 [256] (persistent, added to) or [n,256] when per_frame_hist."""
+        import torch
+        n, p, s, fs = _geom(disp, 1)
+        out = torch.empty_like(disp)
+        _, op, os_, ofs = _geom(out, 1)
+        if hist.dtype != torch.int32 or not hist.is_contiguous():
+            raise EngineError("hist must be a contiguous int32 tensor")
+        self._check(self._lib.cart_plane_derivative_hist(self._h, n, p, s, fs, op, os_, ofs, C.c_void_p(hist.data_ptr()),
+                                                         256 if per_frame_hist else 0, _stream_ptr()),
+                    "cart_plane_derivative_hist")
+        return out
+
+    def plane_classify(self, deriv, params):
+        """params: one PlaneParams / 6-tuple, or a list with one per frame."""
+        import torch
+        n, p, s, fs = _geom(deriv, 1)
+        per_frame = isinstance(params, (list,)) and len(params) == n and n > 1
+        plist = params if isinstance(params, list) else [params]
+        arr = (PlaneParams * len(plist))()
+        for i, q in enumerate(plist):
+            arr[i] = q if isinstance(q, PlaneParams) else PlaneParams(*q)
+        planes = torch.empty(deriv.shape, dtype=torch.uint8, device=deriv.device)
+        _, pp, ps, pfs = _geom(planes, 1)
+        self._check(self._lib.cart_plane_classify(self._h, n, p, s, fs, arr, 1 if per_frame else 0, pp, ps, pfs,
+                                                  _stream_ptr()), "cart_plane_classify")
+        return planes
+
+    def plane_ccl(self, planes):
+        import torch
+        n, p, s, fs = _geom(planes, 1)
+        ids = torch.empty(planes.shape, dtype=torch.int32, device=planes.device)
+        ncomp = torch.empty((n,), dtype=torch.int32, device=planes.device)
+        _, ip, is_, ifs = _geom(ids, 1)
+        self._check(self._lib.cart_plane_ccl(self._h, n, p, s, fs, ip, is_, ifs, C.c_void_p(ncomp.data_ptr()),
+                                             _stream_ptr()), "cart_plane_ccl")
+        return ids, ncomp
+
+    # ---- diagnostics ----
+    def debug_read(self, what, frame_slot=0):
+        lib = self._lib
+        npx = self.width * self.height
+        if what in (0, 1):
+            buf = np.empty((self.height, self.width), np.uint8)
+        elif what in (2, 3):
+            buf = np.empty((self.height, self.width), np.uint32)
+        elif 16 <= what < 16 + self.P:
+            buf = np.empty((self.height, self.width, self.D), np.uint8)
+        elif what in (32, 33):
+            buf = np.empty((self.height, self.width), np.uint16)
+        else:
+            raise EngineError("unknown debug selector")
+        assert buf.size >= npx
+        self._check(lib.cart_debug_read(self._h, frame_slot, what, buf.ctypes.data_as(C.c_void_p), buf.nbytes),
+                    "cart_debug_read")
+        return buf
+
+    def set_timing(self, enabled=True):
+        self._check(self._lib.cart_engine_set_timing(self._h, 1 if enabled else 0), "cart_engine_set_timing")
+
+    def last_timing(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self._lib.cart_engine_last_timing(self._h, names, ms, 16)
+        if n < 0:
+            raise EngineError("cart_engine_last_timing: " + self._lib.cart_last_error(self._h).decode())
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+def find_plane_params(hist256, params=None):
+    """HOST: reference HistogramPeakPlaneParameterProvider::updatePlaneParameters (planeseg.cu:405-458).
+    -> (updated: bool, PlaneParams)."""
+    lib = _lib.load()
+    h = np.ascontiguousarray(np.asarray(hist256, dtype=np.int32).reshape(256))
+    p = PlaneParams(*(params.as_tuple() if isinstance(params, PlaneParams) else (params or (0,) * 6)))
+    rc = lib.cart_find_plane_params(h.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(p))
+    if rc < 0:
+        raise EngineError("cart_find_plane_params: " + lib.cart_last_error(None).decode())
+    return bool(rc), p
+
+
+def find_peaks(data):
+    """HOST: reference util::findPeaks (src/utils/peaks.cpp:12-72) -> list of (born, died, left, right)."""
+    lib = _lib.load()
+    d = np.ascontiguousarray(np.asarray(data, dtype=np.int32).ravel())
+    n = d.size
+    arrs = [(C.c_int * n)() for _ in range(4)]
+    k = lib.cart_find_peaks(d.ctypes.data_as(C.POINTER(C.c_int32)), n, *arrs)
+    if k < 0:
+        raise EngineError("cart_find_peaks: " + lib.cart_last_error(None).decode())
+    return [tuple(a[i] for a in arrs) for i in range(k)]

@@ -1,0 +1,554 @@
+// cart_engine.hip -- C-ABI implementation (include/cart_engine.h): workspace pool, stage
+// sequencing and the host-side peak finder.  No exceptions cross the ABI and nothing exits.
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine_internal.h"
+
+using namespace cart_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+thread_local int g_last_slot = 0;  // first slot of this thread's most recent compute lease
+
+int fail(const std::string &msg) {
+    g_last_error = msg;
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                        std::to_string(__LINE__) + ")");                                           \
+    } while (0)
+
+struct Slot {
+    bool busy = false;
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+
+constexpr int kMaxTimings = 16;
+
+}  // namespace
+
+struct cart_engine {
+    cart_engine_params params;
+    Geometry g;
+    float uniq;
+    // workspaces, each [max_inflight][...]
+    uint8_t *gray_l = nullptr, *gray_r = nullptr;
+    uint32_t *cen_l = nullptr, *cen_r = nullptr;
+    uint8_t *slabs = nullptr;
+    uint16_t *wta_l = nullptr;
+    uint32_t *right_pk = nullptr;
+    int16_t *tmp_a = nullptr, *tmp_b = nullptr;  // tight s16 planes (interpolate ping-pong)
+    int32_t *ccl_work = nullptr;
+    AggArgs agg;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slot> slots;
+    bool timing = false;
+    // timing of the last compute call (any thread; guarded by mu)
+    hipEvent_t tev[kMaxTimings + 1] = {};
+    const char *tnames[kMaxTimings] = {};
+    int ntimes = 0;
+    hipStream_t tstream = nullptr;
+};
+
+namespace {
+
+struct Lease {
+    cart_engine *e;
+    int s0, n;
+    hipStream_t stream;
+};
+
+// Leases `n` contiguous slots; makes `stream` wait for earlier work on them from other streams.
+int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
+    if (n <= 0 || n > (int)e->slots.size()) return fail("n_frames must be in [1, max_inflight]");
+    std::unique_lock<std::mutex> lk(e->mu);
+    int s0 = -1;
+    for (;;) {
+        const int total = (int)e->slots.size();
+        for (int i = 0; i + n <= total && s0 < 0; ++i) {
+            bool ok = true;
+            for (int k = 0; k < n; ++k)
+                if (e->slots[i + k].busy) { ok = false; i += k; break; }
+            if (ok) s0 = i;
+        }
+        if (s0 >= 0) break;
+        e->cv.wait(lk);
+    }
+    for (int k = 0; k < n; ++k) e->slots[s0 + k].busy = true;
+    lk.unlock();
+    for (int k = 0; k < n; ++k) {
+        Slot &s = e->slots[s0 + k];
+        if (s.used && s.last_stream != stream) {
+            hipError_t err = hipStreamWaitEvent(stream, s.done, 0);
+            if (err != hipSuccess) return fail(std::string("hipStreamWaitEvent: ") + hipGetErrorString(err));
+        }
+    }
+    out->e = e; out->s0 = s0; out->n = n; out->stream = stream;
+    return 0;
+}
+
+void release(const Lease &l) {
+    cart_engine *e = l.e;
+    for (int k = 0; k < l.n; ++k) {
+        Slot &s = e->slots[l.s0 + k];
+        (void)hipEventRecord(s.done, l.stream);
+        s.last_stream = l.stream;
+        s.used = true;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (int k = 0; k < l.n; ++k) e->slots[l.s0 + k].busy = false;
+    }
+    e->cv.notify_all();
+}
+
+void build_agg_args(cart_engine *e) {
+    AggArgs &a = e->agg;
+    const Geometry &g = e->g;
+    a.g = g;
+    // launch order: the long serial scans (horizontal, W steps) get the lowest block ids so they
+    // start first; slab index `path` keeps the oracle's order {down, up, right, left, diagonals}.
+    struct D { int dx, dy, path; };
+    static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
+    a.ndirs = g.P;
+    int blk = 0;
+    for (int i = 0; i < g.P; ++i) {
+        DirDesc &d = a.dirs[i];
+        d.dx = order8[i].dx; d.dy = order8[i].dy; d.path = order8[i].path;
+        if (d.dy == 0) { d.nlines = g.h; d.jmin = 0; }
+        else if (d.dx == 0) { d.nlines = g.w; d.jmin = 0; }
+        else { d.nlines = g.w + g.h - 1; d.jmin = d.dx > 0 ? -(g.h - 1) : 0; }
+        d.blk0 = blk;
+        blk += (d.nlines + kLinesPerBlock - 1) / kLinesPerBlock;
+    }
+    a.blocks_per_frame = blk;
+    a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
+}
+
+int validate(const cart_engine_params *p) {
+    if (!p) return fail("params is NULL");
+    if (p->width < 16 || p->height < 8 || p->width > 16384 || p->height > 16384) return fail("unsupported image size");
+    if (!(p->num_disparities == 64 || p->num_disparities == 128 || p->num_disparities == 256))
+        return fail("num_disparities must be 64, 128 or 256");
+    if (!(p->paths == 4 || p->paths == 8)) return fail("paths must be 4 or 8");
+    if (p->min_disparity < 0 || p->min_disparity > 64) return fail("min_disparity must be in [0, 64]");
+    if (p->p1 < 0 || p->p2 < p->p1 || p->p2 + 31 > 255) return fail("need 0 <= p1 <= p2 and 31 + p2 <= 255");
+    if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100) return fail("uniqueness_ratio must be in [0, 100]");
+    if (p->smoothing_radius > 8) return fail("smoothing_radius must be <= 8");
+    if (p->max_inflight < 1 || p->max_inflight > 4096) return fail("max_inflight must be in [1, 4096]");
+    return 0;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cart_engine_default_params(cart_engine_params *p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->device_id = 0;
+    p->min_disparity = 4;       // cartconfig.cpp:147
+    p->num_disparities = 256;   // cartconfig.cpp:148
+    p->paths = 4;               // cv::cuda::createStereoSGM default mode MODE_HH4
+    p->p1 = 10; p->p2 = 120;    // cv::cuda::createStereoSGM defaults
+    p->uniqueness_ratio = 12;   // disparity.hpp:32
+    p->smoothing_radius = -1;   // cartconfig.cpp:150
+    p->smoothing_iterations = 5;  // cartconfig.cpp:151
+    p->max_inflight = 12;       // CARTSLAM_CONCURRENT_RUN_LIMIT, cartslam.hpp:4
+}
+
+int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (validate(params)) return -1;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (params->device_id < 0 || params->device_id >= ndev) return fail("device_id out of range (no such GPU)");
+    HIP_TRY(hipSetDevice(params->device_id));
+    cart_engine *e = new (std::nothrow) cart_engine();
+    if (!e) return fail("out of host memory");
+    e->params = *params;
+    Geometry &g = e->g;
+    g.w = params->width; g.h = params->height; g.D = params->num_disparities; g.P = params->paths;
+    g.min_disp = params->min_disparity; g.p1 = params->p1; g.p2 = params->p2;
+    g.cpadl = ((g.min_disp + g.D + 15) / 16) * 16;
+    g.cpitch = ((g.cpadl + g.w + 16 + 15) / 16) * 16;
+    g.npx = (size_t)g.w * g.h;
+    g.census_elems = (size_t)g.h * g.cpitch;
+    g.slab_bytes = g.npx * g.D;
+    e->uniq = (float)(100 - params->uniqueness_ratio) / 100.0f;  // oracle S5
+    const size_t n = (size_t)params->max_inflight;
+    int rc = 0;
+    rc |= dev_alloc(&e->gray_l, n * g.npx);
+    rc |= dev_alloc(&e->gray_r, n * g.npx);
+    rc |= dev_alloc(&e->cen_l, n * g.census_elems);
+    rc |= dev_alloc(&e->cen_r, n * g.census_elems);
+    rc |= dev_alloc(&e->slabs, n * g.P * g.slab_bytes);
+    rc |= dev_alloc(&e->wta_l, n * g.npx);
+    rc |= dev_alloc(&e->right_pk, n * g.npx);
+    rc |= dev_alloc(&e->tmp_a, n * g.npx);
+    rc |= dev_alloc(&e->tmp_b, n * g.npx);
+    rc |= dev_alloc(&e->ccl_work, n * g.npx);
+    if (rc) { cart_engine_destroy(e); return -1; }
+    // the census padding columns are never written again: out-of-image right features read as 0 (oracle S3)
+    if (hipMemset(e->cen_l, 0, n * g.census_elems * 4) != hipSuccess ||
+        hipMemset(e->cen_r, 0, n * g.census_elems * 4) != hipSuccess) {
+        cart_engine_destroy(e);
+        return fail("hipMemset of census workspace failed");
+    }
+    e->slots.resize(n);
+    for (auto &s : e->slots)
+        if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+            cart_engine_destroy(e);
+            return fail("hipEventCreate failed");
+        }
+    for (auto &ev : e->tev)
+        if (hipEventCreate(&ev) != hipSuccess) { cart_engine_destroy(e); return fail("hipEventCreate failed"); }
+    build_agg_args(e);
+    *out = e;
+    return 0;
+}
+
+void cart_engine_destroy(cart_engine *e) {
+    if (!e) return;
+    (void)hipDeviceSynchronize();
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l, e->cen_r, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto &s : e->slots)
+        if (s.done) (void)hipEventDestroy(s.done);
+    for (auto &ev : e->tev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+const char *cart_last_error(const cart_engine *) { return g_last_error.c_str(); }
+
+const char *cart_engine_version(void) {
+    static char buf[64];
+    std::snprintf(buf, sizeof(buf), "cart_engine gfx950 %d kernels", kernel_count());
+    return buf;
+}
+
+int cart_engine_set_timing(cart_engine *e, int enabled) {
+    if (!e) return fail("engine is NULL");
+    e->timing = enabled != 0;
+    return 0;
+}
+
+int cart_engine_last_timing(cart_engine *e, const char **names, float *ms, int cap) {
+    if (!e) return fail("engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->ntimes == 0) return 0;
+    if (hipEventSynchronize(e->tev[e->ntimes]) != hipSuccess) return fail("hipEventSynchronize failed");
+    int n = std::min(cap, e->ntimes);
+    for (int i = 0; i < n; ++i) {
+        names[i] = e->tnames[i];
+        if (hipEventElapsedTime(&ms[i], e->tev[i], e->tev[i + 1]) != hipSuccess) return fail("hipEventElapsedTime failed");
+    }
+    return n;
+}
+
+#define STAGE(name)                                                        \
+    do {                                                                   \
+        if (timed && nt < kMaxTimings) {                                   \
+            (void)hipEventRecord(e->tev[nt], stream);                      \
+            e->tnames[nt] = name;                                          \
+            ++nt;                                                          \
+        }                                                                  \
+    } while (0)
+
+int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
+                                 size_t left_frame_stride, const uint8_t *right, size_t right_step,
+                                 size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
+                                 size_t out_frame_stride, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!left || !right || !out) return fail("NULL image pointer");
+    if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
+    const Geometry &g = e->g;
+    if (left_step < (size_t)g.w * channels || right_step < (size_t)g.w * channels) return fail("input step smaller than a row");
+    if (out_step < (size_t)g.w * 2 || (out_step & 1)) return fail("out_step must be even and >= 2*width");
+    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    Lease l;
+    if (acquire(e, n_frames, stream, &l)) return -1;
+    g_last_slot = l.s0;
+    const bool timed = e->timing;
+    int nt = 0;
+    const size_t s0 = (size_t)l.s0;
+    uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
+    uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
+    uint8_t *slabs = e->slabs + s0 * g.P * g.slab_bytes;
+    uint16_t *wl = e->wta_l + s0 * g.npx;
+    uint32_t *rpk = e->right_pk + s0 * g.npx;
+    int16_t *ta = e->tmp_a + s0 * g.npx, *tb = e->tmp_b + s0 * g.npx;
+
+    STAGE("census");
+    ImageBatch lb{left, left_step, left_frame_stride}, rb{right, right_step, right_frame_stride};
+    launch_census(lb, rb, channels, n_frames, gl, gr, cl, cr, rpk, g, stream);
+    STAGE("aggregate");
+    AggArgs a = e->agg;
+    a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
+    launch_aggregate(a, n_frames, stream);
+    STAGE("wta");
+    launch_wta(slabs, wl, rpk, g, e->uniq, n_frames, stream);
+    STAGE("post");
+    const int radius = e->params.smoothing_radius, iters = e->params.smoothing_iterations;
+    const bool smooth = radius > 0 && iters > 0;  // disparity.cu:73
+    const size_t tight_step = (size_t)g.w * 2, tight_fs = g.npx * 2;
+    if (!smooth) {
+        launch_post(wl, rpk, gl, out, out_step, out_frame_stride, g, n_frames, stream);
+    } else {
+        launch_post(wl, rpk, gl, ta, tight_step, tight_fs, g, n_frames, stream);
+        STAGE("interpolate");
+        // disparity.hpp:27-28: minDisparity = cfg*16, maxDisparity = image width (not x16)
+        const int min16 = e->params.min_disparity * 16, maxd = g.w;
+        int16_t *src = ta, *dst = tb;
+        for (int it = 0; it < iters; ++it) {
+            const bool last = it == iters - 1;
+            if (last) launch_interpolate(src, tight_step, tight_fs, out, out_step, out_frame_stride, g.w, g.h, radius, min16, maxd, n_frames, stream);
+            else launch_interpolate(src, tight_step, tight_fs, dst, tight_step, tight_fs, g.w, g.h, radius, min16, maxd, n_frames, stream);
+            std::swap(src, dst);
+        }
+    }
+    if (timed) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        (void)hipEventRecord(e->tev[nt], stream);
+        e->ntimes = nt;
+    }
+    hipError_t err = hipGetLastError();
+    release(l);
+    if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
+    return 0;
+}
+
+int cart_compute_disparity(cart_engine *e, const uint8_t *left, size_t left_step, const uint8_t *right,
+                           size_t right_step, int channels, int16_t *out, size_t out_step, void *stream) {
+    return cart_compute_disparity_batch(e, 1, left, left_step, 0, right, right_step, 0, channels, out, out_step, 0, stream);
+}
+
+int cart_interpolate(cart_engine *e, int n_frames, int16_t *disp, size_t step, size_t frame_stride, int radius,
+                     int iterations, int min_disp16, int max_disp, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!disp) return fail("NULL image pointer");
+    if (radius <= 0 || iterations <= 0) return 0;
+    if (radius > 8) return fail("radius must be <= 8");
+    const Geometry &g = e->g;
+    if (step < (size_t)g.w * 2 || (step & 1) || (frame_stride & 1)) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    Lease l;
+    if (acquire(e, n_frames, stream, &l)) return -1;
+    int16_t *ta = e->tmp_a + (size_t)l.s0 * g.npx, *tb = e->tmp_b + (size_t)l.s0 * g.npx;
+    const size_t ts = (size_t)g.w * 2, tfs = g.npx * 2;
+    // pass 0 reads the caller's buffer, the last pass writes it; an extra tight copy keeps Jacobi semantics
+    launch_interpolate(disp, step, frame_stride, ta, ts, tfs, g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
+    int16_t *src = ta, *dst = tb;
+    for (int it = 1; it < iterations; ++it) {
+        launch_interpolate(src, ts, tfs, dst, ts, tfs, g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
+        std::swap(src, dst);
+    }
+    hipError_t err = hipSuccess;
+    for (int f = 0; f < n_frames && err == hipSuccess; ++f)
+        err = hipMemcpy2DAsync(reinterpret_cast<uint8_t *>(disp) + (size_t)f * frame_stride, step, src + (size_t)f * g.npx, ts, ts,
+                               g.h, hipMemcpyDeviceToDevice, stream);
+    if (err == hipSuccess) err = hipGetLastError();
+    release(l);
+    if (err != hipSuccess) return fail(std::string("interpolate failed: ") + hipGetErrorString(err));
+    return 0;
+}
+
+int cart_disparity_derivative(cart_engine *e, int n_frames, const int16_t *disp, size_t disp_step,
+                              size_t disp_frame_stride, int16_t *out, size_t out_step, size_t out_frame_stride,
+                              int32_t *hist512, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!disp || !out || !hist512) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (disp_step < (size_t)g.w * 2 || out_step < (size_t)g.w * 4 || (out_step & 3) || (out_frame_stride & 3) || (disp_step & 1) || (disp_frame_stride & 1))
+        return fail("bad step (derivative rows must be 4-byte aligned)");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    launch_dir_derivative(disp, disp_step, disp_frame_stride, out, out_step, out_frame_stride, hist512, g.w, g.h, n_frames,
+                          static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_plane_derivative_hist(cart_engine *e, int n_frames, const int16_t *disp, size_t disp_step,
+                               size_t disp_frame_stride, int16_t *out, size_t out_step, size_t out_frame_stride,
+                               int32_t *hist256, size_t hist_frame_stride_elems, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!disp || !out || !hist256) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (disp_step < (size_t)g.w * 2 || out_step < (size_t)g.w * 2 || (disp_step & 1) || (out_step & 1) || (disp_frame_stride & 1) || (out_frame_stride & 1))
+        return fail("bad step");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    launch_plane_derivative(disp, disp_step, disp_frame_stride, out, out_step, out_frame_stride, hist256,
+                            hist_frame_stride_elems, g.w, g.h, n_frames, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_plane_classify(cart_engine *e, int n_frames, const int16_t *deriv, size_t deriv_step, size_t deriv_frame_stride,
+                        const cart_plane_params *params, int params_per_frame, uint8_t *planes, size_t planes_step,
+                        size_t planes_frame_stride, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!deriv || !planes || !params) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (deriv_step < (size_t)g.w * 2 || planes_step < (size_t)g.w || (deriv_step & 1) || (deriv_frame_stride & 1)) return fail("bad step");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxBatchArgs) {
+        const int n = std::min(kMaxBatchArgs, n_frames - f0);
+        ClassifyParams cp;
+        if (params_per_frame) std::memcpy(cp.p, params + f0, sizeof(cart_plane_params) * (size_t)n);
+        else cp.p[0] = params[0];
+        launch_classify(reinterpret_cast<const int16_t *>(reinterpret_cast<const uint8_t *>(deriv) + (size_t)f0 * deriv_frame_stride),
+                        deriv_step, deriv_frame_stride, cp, params_per_frame, planes + (size_t)f0 * planes_frame_stride,
+                        planes_step, planes_frame_stride, g.w, g.h, n, stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_plane_ccl(cart_engine *e, int n_frames, const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
+                   int32_t *ids, size_t ids_step, size_t ids_frame_stride, int32_t *n_components, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!planes || !ids) return fail("NULL pointer");
+    const Geometry &g = e->g;
+    if (planes_step < (size_t)g.w || ids_step < (size_t)g.w * 4 || (ids_step & 3) || (ids_frame_stride & 3)) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    Lease l;
+    if (acquire(e, n_frames, stream, &l)) return -1;
+    launch_ccl(planes, planes_step, planes_frame_stride, e->ccl_work + (size_t)l.s0 * g.npx, ids, ids_step, ids_frame_stride,
+               n_components, g.w, g.h, n_frames, stream);
+    hipError_t err = hipGetLastError();
+    release(l);
+    if (err != hipSuccess) return fail(std::string("ccl failed: ") + hipGetErrorString(err));
+    return 0;
+}
+
+// ---- host-side peak finder (replaces src/utils/peaks.cpp:12-72 and planeseg.cu:405-458) ----
+int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right) {
+    if (!data || n <= 0 || !born || !died || !left || !right) return fail("bad arguments");
+    std::vector<int> order(n), owner(n, -1);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    // descending value, ties by ascending index (oracle S11; the reference's std::sort leaves ties open)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return data[a] > data[b]; });
+    int np = 0;
+    for (int idx : order) {
+        const int il = (idx > 0) ? owner[idx - 1] : -1;
+        const int ir = (idx < n - 1) ? owner[idx + 1] : -1;
+        if (il < 0 && ir < 0) {  // a new component is born at a local maximum
+            born[np] = left[np] = right[np] = idx; died[np] = -1;
+            owner[idx] = np++;
+        } else if (il >= 0 && ir < 0) {
+            right[il] += 1; owner[idx] = il;
+        } else if (il < 0 && ir >= 0) {
+            left[ir] -= 1; owner[idx] = ir;
+        } else if (data[born[il]] > data[born[ir]]) {  // the younger (lower) peak dies at this saddle
+            died[ir] = idx; right[il] = right[ir];
+            owner[right[il]] = owner[idx] = il;
+        } else {
+            died[il] = idx; left[ir] = left[il];
+            owner[left[ir]] = owner[idx] = ir;
+        }
+    }
+    std::vector<int> perm(np);
+    for (int i = 0; i < np; ++i) perm[i] = i;
+    auto persistence = [&](int k) -> long long { return died[k] < 0 ? (long long)INT32_MAX : (long long)data[born[k]] - data[died[k]]; };
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return persistence(a) > persistence(b); });
+    std::vector<int> b2(np), d2(np), l2(np), r2(np);
+    for (int i = 0; i < np; ++i) { b2[i] = born[perm[i]]; d2[i] = died[perm[i]]; l2[i] = left[perm[i]]; r2[i] = right[perm[i]]; }
+    for (int i = 0; i < np; ++i) { born[i] = b2[i]; died[i] = d2[i]; left[i] = l2[i]; right[i] = r2[i]; }
+    return np;
+}
+
+int cart_find_plane_params(const int32_t hist[256], cart_plane_params *io) {
+    if (!hist || !io) return fail("bad arguments");
+    int born[256], died[256], left[256], right[256];
+    const int np = cart_find_peaks(hist, 256, born, died, left, right);
+    if (np < 2) return 0;  // planeseg.cu:408-411
+    int pv = born[0], ph = born[1];
+    if (std::abs(pv - 128) > std::abs(ph - 128)) std::swap(pv, ph);  // vertical = nearer to zero derivative (:414-416)
+    io->vertical_center = pv - 128;
+    io->horizontal_center = ph - 128;
+    int valley = std::min(pv, ph);
+    for (int i = valley; i < std::max(pv, ph); ++i)
+        if (hist[i] < hist[valley]) valley = i;  // :422-428
+    const int vdist = std::abs(valley - pv), hdist = std::abs(valley - ph);
+    if (vdist == 0 || hdist == 0) return 0;  // :436-439
+    const int vslope = (hist[pv] - hist[valley]) / vdist, hslope = (hist[ph] - hist[valley]) / hdist;
+    if (vslope == 0 || hslope == 0) return 0;  // :444-447
+    const int vwidth = hist[pv] / vslope, hwidth = hist[ph] / hslope;
+    io->vertical_min = pv - vwidth - 128; io->vertical_max = valley - 127;      // :452
+    io->horizontal_min = valley - 127; io->horizontal_max = ph + hwidth - 127;  // :453
+    return 1;
+}
+
+int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, size_t bytes) {
+    if (!e || !host_dst) return fail("bad arguments");
+    const Geometry &g = e->g;
+    const int slot = g_last_slot + frame_slot;
+    if (frame_slot < 0 || slot >= (int)e->slots.size()) return fail("frame_slot out of range");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const void *src = nullptr;
+    size_t need = 0;
+    if (what == CART_DBG_GRAY_L || what == CART_DBG_GRAY_R) {
+        src = (what == CART_DBG_GRAY_L ? e->gray_l : e->gray_r) + (size_t)slot * g.npx; need = g.npx;
+        if (bytes < need) return fail("buffer too small");
+        HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    } else if (what == CART_DBG_CENSUS_L || what == CART_DBG_CENSUS_R) {
+        const uint32_t *c = (what == CART_DBG_CENSUS_L ? e->cen_l : e->cen_r) + (size_t)slot * g.census_elems + g.cpadl;
+        need = g.npx * 4;
+        if (bytes < need) return fail("buffer too small");
+        HIP_TRY(hipMemcpy2D(host_dst, (size_t)g.w * 4, c, (size_t)g.cpitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
+    } else if (what >= CART_DBG_PATH0 && what < CART_DBG_PATH0 + g.P) {
+        src = e->slabs + ((size_t)slot * g.P + (what - CART_DBG_PATH0)) * g.slab_bytes; need = g.slab_bytes;
+        if (bytes < need) return fail("buffer too small");
+        HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    } else if (what == CART_DBG_WTA_L) {
+        src = e->wta_l + (size_t)slot * g.npx; need = g.npx * 2;
+        if (bytes < need) return fail("buffer too small");
+        HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+    } else if (what == CART_DBG_WTA_R) {  // packed (cost<<16 | disparity) -> u16 disparity
+        std::vector<uint32_t> tmp(g.npx);
+        need = g.npx * 2;
+        if (bytes < need) return fail("buffer too small");
+        HIP_TRY(hipMemcpy(tmp.data(), e->right_pk + (size_t)slot * g.npx, g.npx * 4, hipMemcpyDeviceToHost));
+        uint16_t *d = static_cast<uint16_t *>(host_dst);
+        for (size_t i = 0; i < g.npx; ++i) d[i] = (uint16_t)(tmp[i] & 0xffffu);
+    } else {
+        return fail("unknown debug selector");
+    }
+    return 0;
+}
+
+}  // extern "C"

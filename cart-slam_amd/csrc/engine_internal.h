@@ -1,0 +1,78 @@
+// engine_internal.h -- shared declarations between the C-ABI host code and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cart_engine.h"
+
+namespace cart_amd {
+
+constexpr int kMaxPaths = 8;
+constexpr int kLinesPerBlock = 16;   // one 16-lane DPP row per scan line, 256-thread blocks
+constexpr int kWtaTileX = 64;        // pixels of one row handled by one WTA block
+constexpr int kMaxBatchArgs = 128;   // frames per classify launch (params travel as kernel args)
+constexpr uint32_t kWtaInvalid = 0xFFFFu;
+
+// Geometry of one engine instance; all buffers below are per workspace slot (= frame).
+struct Geometry {
+    int w, h, D, P;
+    int min_disp, p1, p2;
+    int cpitch;          // census row pitch in u32 elements (zero padded left/right)
+    int cpadl;           // index of image column 0 inside a census row
+    size_t npx;          // w*h
+    size_t census_elems; // h*cpitch
+    size_t slab_bytes;   // npx*D (one path)
+};
+
+// One scan direction inside the fused path-aggregation launch.
+struct DirDesc {
+    int dx, dy;
+    int nlines;   // number of scan lines
+    int jmin;     // line index of line 0 (skewed start column, or row for horizontal paths)
+    int blk0;     // first block of this direction
+    int path;     // slab index (oracle order: down, up, right, left, diagonals)
+};
+
+struct AggArgs {
+    const uint32_t *cen_l, *cen_r;   // slot 0 of the lease
+    uint8_t *slabs;                  // [slot][path][h][w][D]
+    Geometry g;
+    int ndirs;
+    int blocks_per_frame;
+    DirDesc dirs[kMaxPaths];
+};
+
+struct ImageBatch {   // pitched caller image(s)
+    const uint8_t *ptr;
+    size_t step, frame_stride;
+};
+
+// ---- launchers (sgm_kernels.hip) ----
+void launch_census(const ImageBatch &left, const ImageBatch &right, int channels, int n_frames,
+                   uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l, uint32_t *cen_r, uint32_t *right_pk,
+                   const Geometry &g, hipStream_t s);
+void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
+void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
+                int n_frames, hipStream_t s);
+void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, int16_t *out,
+                 size_t out_step, size_t out_frame_stride, const Geometry &g, int n_frames, hipStream_t s);
+
+// ---- launchers (post_kernels.hip) ----
+void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
+                        size_t dst_fs, int w, int h, int radius, int min_disp16, int max_disp, int n_frames,
+                        hipStream_t s);
+void launch_dir_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
+                           int32_t *hist512, int w, int h, int n_frames, hipStream_t s);
+void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
+                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s);
+struct ClassifyParams { cart_plane_params p[kMaxBatchArgs]; };
+void launch_classify(const int16_t *deriv, size_t step, size_t fs, const ClassifyParams &params, int per_frame,
+                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s);
+void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
+                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
+
+int kernel_count();
+
+}  // namespace cart_amd

@@ -1,0 +1,241 @@
+// post_kernels.hip -- gfx950 kernels for the stages after the SGM core.
+//
+// Each kernel restates one of the reference's own CUDA kernels under the clean "intent"
+// semantics fixed in SURVEY.md 8c (Jacobi reads of the unmodified input, no tile row-shift,
+// out-of-image samples skipped by window means / making a difference INVALID):
+//   interpolate_kernel        <- interpolateKernel        src/modules/disparity/interpolation.cu:17-82
+//   dir_derivative_kernel     <- calculateDirectionalDerivatives + mergeDerivativeHistograms
+//                                                           src/modules/disparity/derivative.cu:27-116
+//   plane_derivative_kernel   <- calculateDerivatives + mergeHistogram   src/modules/planeseg/planeseg.cu:31-158
+//   classify_kernel           <- classifyPlanes (non-temporal)           src/modules/planeseg/planeseg.cu:160-198
+//   ccl_*                     <- new stage (no reference counterpart), spec S12 in oracle/cart_oracle.h
+// Images are small (<= 4 MB) and L2 resident; the kernels are one-pass, coalesced along x, with
+// block-local LDS histograms flushed by one global atomicAdd per bin and block.
+#include <type_traits>
+
+#include "engine_internal.h"
+
+namespace cart_amd {
+
+constexpr int INVALID = CART_DISPARITY_INVALID;
+
+template <typename T>
+__device__ __forceinline__ T *row_ptr(T *base, size_t frame_stride, size_t step, int frame, int y) {
+    typedef typename std::conditional<std::is_const<T>::value, const uint8_t, uint8_t>::type B;
+    return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (size_t)frame * frame_stride + (size_t)y * step);
+}
+
+// ------------------------------------------------------------------ interpolate (one Jacobi pass)
+__global__ __launch_bounds__(256) void interpolate_kernel(const int16_t *src, size_t src_step, size_t src_fs,
+                                                          int16_t *dst, size_t dst_step, size_t dst_fs, int w, int h,
+                                                          int radius, int min_disp16, int max_disp) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    int sum = 0, count = 0;
+    for (int l = -radius + 1; l < radius; ++l) {
+        const int yy = y + l;
+        if (yy < 0 || yy >= h) continue;
+        const int16_t *row = row_ptr(src, src_fs, src_step, frame, yy);
+        for (int k = -radius + 1; k < radius; ++k) {
+            const int xx = x + k;
+            if (xx < 0 || xx >= w) continue;
+            const int v = row[xx];
+            if (v > min_disp16 && v < max_disp) { sum += v; ++count; }
+        }
+    }
+    const unsigned min_count = (unsigned)(radius * radius + 1);  // interpolation.cu:33
+    row_ptr(dst, dst_fs, dst_step, frame, y)[x] = ((unsigned)count > min_count) ? (int16_t)(sum / count) : (int16_t)INVALID;
+}
+
+void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
+                        size_t dst_fs, int w, int h, int radius, int min_disp16, int max_disp, int n_frames,
+                        hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    hipLaunchKernelGGL(interpolate_kernel, grid, block, 0, s, src, src_step, src_fs, dst, dst_step, dst_fs, w, h,
+                       radius, min_disp16, max_disp);
+}
+
+// ------------------------------------------------------------------ directional derivatives + 2x256 histogram
+__global__ __launch_bounds__(256) void dir_derivative_kernel(const int16_t *disp, size_t step, size_t fs, int16_t *out,
+                                                             size_t ostep, size_t ofs, int32_t *hist512, int w, int h) {
+    __shared__ int lh[512];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    lh[tid] = 0; lh[tid + 256] = 0;
+    __syncthreads();
+    const int x = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.z;
+    for (int r = 0; r < 4; ++r) {
+        const int y = blockIdx.y * 16 + threadIdx.y * 4 + r;
+        if (x >= w || y >= h) continue;
+        int dv = INVALID, dh = INVALID;
+        if (y - 2 >= 0 && y + 2 < h) {
+            const int a = row_ptr(disp, fs, step, frame, y + 2)[x], b = row_ptr(disp, fs, step, frame, y - 2)[x];
+            if (a != INVALID && b != INVALID) {
+                dv = (int16_t)(a - b);
+                if (dv >= -128 && dv <= 127) atomicAdd(&lh[2 * (dv + 128)], 1);
+            }
+        }
+        if (x - 2 >= 0 && x + 2 < w) {
+            const int16_t *row = row_ptr(disp, fs, step, frame, y);
+            const int a = row[x + 2], b = row[x - 2];
+            if (a != INVALID && b != INVALID) {
+                dh = (int16_t)(a - b);
+                if (dh >= -128 && dh <= 127) atomicAdd(&lh[2 * (dh + 128) + 1], 1);
+            }
+        }
+        int16_t *orow = row_ptr(out, ofs, ostep, frame, y);
+        *reinterpret_cast<short2 *>(orow + 2 * x) = make_short2((short)dv, (short)dh);
+    }
+    __syncthreads();
+    int32_t *gh = hist512 + (size_t)frame * 512;
+    if (lh[tid]) atomicAdd(&gh[tid], lh[tid]);
+    if (lh[tid + 256]) atomicAdd(&gh[tid + 256], lh[tid + 256]);
+}
+
+void launch_dir_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
+                           int32_t *hist512, int w, int h, int n_frames, hipStream_t s) {
+    (void)hipMemsetAsync(hist512, 0, sizeof(int32_t) * 512 * (size_t)n_frames, s);  // fresh histogram per frame (derivative.cu:169)
+    dim3 grid((w + 63) / 64, (h + 15) / 16, n_frames), block(64, 4);
+    hipLaunchKernelGGL(dir_derivative_kernel, grid, block, 0, s, disp, step, fs, out, ostep, ofs, hist512, w, h);
+}
+
+// ------------------------------------------------------------------ plane derivative (5-tap vertical mean, 1-px diff)
+__device__ __forceinline__ int lowpass5(const int16_t *disp, size_t step, size_t fs, int frame, int x, int y, int h) {
+    if (y < 0 || y >= h) return INVALID;
+    int16_t sum = 0;  // derivative_t accumulator: wraps exactly like planeseg.cu:62
+    int count = 0;
+#pragma unroll
+    for (int k = -2; k <= 2; ++k) {
+        const int yy = y + k;
+        if (yy < 0 || yy >= h) continue;
+        const int16_t v = row_ptr(disp, fs, step, frame, yy)[x];
+        if (v != INVALID) { sum = (int16_t)(sum + v); ++count; }
+    }
+    return count == 0 ? INVALID : (int)(int16_t)((int)sum / count);
+}
+
+__global__ __launch_bounds__(256) void plane_derivative_kernel(const int16_t *disp, size_t step, size_t fs, int16_t *out,
+                                                               size_t ostep, size_t ofs, int32_t *hist256, size_t hist_fs,
+                                                               int w, int h) {
+    __shared__ int lh[256];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    lh[tid] = 0;
+    __syncthreads();
+    const int x = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.z;
+    const int ybase = blockIdx.y * 16 + threadIdx.y * 4;
+    if (x < w && ybase < h) {
+        // sliding: lp(y-1), lp(y), lp(y+1) for the 4 rows of this thread
+        int lpm = lowpass5(disp, step, fs, frame, x, ybase - 1, h);
+        int lpc = lowpass5(disp, step, fs, frame, x, ybase, h);
+        for (int r = 0; r < 4; ++r) {
+            const int y = ybase + r;
+            if (y >= h) break;
+            const int lpp = lowpass5(disp, step, fs, frame, x, y + 1, h);
+            int o = INVALID;
+            if (lpm != INVALID && lpc != INVALID && lpp != INVALID) {
+                o = (int16_t)(lpp - lpm);
+                if (o >= -128 && o <= 127) atomicAdd(&lh[o + 128], 1);
+            }
+            row_ptr(out, ofs, ostep, frame, y)[x] = (int16_t)o;
+            lpm = lpc; lpc = lpp;
+        }
+    }
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&hist256[(size_t)frame * hist_fs + tid], lh[tid]);  // cumulative, planeseg.cu:157
+}
+
+void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
+                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 15) / 16, n_frames), block(64, 4);
+    hipLaunchKernelGGL(plane_derivative_kernel, grid, block, 0, s, disp, step, fs, out, ostep, ofs, hist256, hist_fs, w, h);
+}
+
+// ------------------------------------------------------------------ classify
+__global__ __launch_bounds__(256) void classify_kernel(const int16_t *deriv, size_t step, size_t fs, ClassifyParams params,
+                                                       int per_frame, uint8_t *planes, size_t pstep, size_t pfs, int w, int h) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const cart_plane_params pp = params.p[per_frame ? frame : 0];
+    const int d = row_ptr(deriv, fs, step, frame, y)[x];
+    int plane = CART_PLANE_UNKNOWN;
+    if (d != INVALID && d >= pp.horizontal_min && d < pp.horizontal_max) plane = CART_PLANE_HORIZONTAL;
+    else if (d != INVALID && d >= pp.vertical_min && d < pp.vertical_max) plane = CART_PLANE_VERTICAL;
+    row_ptr(planes, pfs, pstep, frame, y)[x] = (uint8_t)plane;
+}
+
+void launch_classify(const int16_t *deriv, size_t step, size_t fs, const ClassifyParams &params, int per_frame,
+                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    hipLaunchKernelGGL(classify_kernel, grid, block, 0, s, deriv, step, fs, params, per_frame, planes, pstep, pfs, w, h);
+}
+
+// ------------------------------------------------------------------ connected components (union-find, min-index roots)
+// Parent links only ever decrease (atomicMin) and always point inside the component, so a stale
+// read (per-XCD L2s are not coherent inside a launch) can only lengthen a walk, never break it;
+// the flatten pass runs in a later launch and therefore sees every link.
+__device__ __forceinline__ int ccl_find(int32_t *L, int i) {
+    int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != i) { i = p; p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return i;
+}
+
+__device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
+    for (int guard = 0; guard < (1 << 24); ++guard) {  // bounded: every retry strictly lowers a root
+        a = ccl_find(L, a); b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_init_kernel(int32_t *work, int w, int h, size_t npx) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    work[(size_t)frame * npx + (size_t)y * w + x] = y * w + x;
+}
+
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
+                                                        int w, int h, size_t npx) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
+    const uint8_t c = row[x];
+    if (c > 1) return;
+    int32_t *L = work + (size_t)frame * npx;
+    const int i = y * w + x;
+    if (x > 0 && row[x - 1] == c) ccl_union(L, i, i - 1);
+    if (y > 0 && row_ptr(planes, pfs, pstep, frame, y - 1)[x] == c) ccl_union(L, i, i - w);
+}
+
+__global__ __launch_bounds__(256) void ccl_flatten_kernel(const uint8_t *planes, size_t pstep, size_t pfs,
+                                                          const int32_t *work, int32_t *ids, size_t istep, size_t ifs,
+                                                          int32_t *ncomp, int w, int h, size_t npx) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const uint8_t c = row_ptr(planes, pfs, pstep, frame, y)[x];
+    const int32_t *L = work + (size_t)frame * npx;
+    int i = y * w + x, r = -1;
+    if (c <= 1) {
+        r = i;
+        int p = L[r];
+        while (p != r) { r = p; p = L[r]; }
+        if (r == i && ncomp) atomicAdd(&ncomp[frame], 1);
+    }
+    row_ptr(ids, ifs, istep, frame, y)[x] = r;
+}
+
+void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
+                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
+    const size_t npx = (size_t)w * h;
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    if (ncomp) (void)hipMemsetAsync(ncomp, 0, sizeof(int32_t) * (size_t)n_frames, s);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, s, work, w, h, npx);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, s, planes, pstep, pfs, work, w, h, npx);
+    hipLaunchKernelGGL(ccl_flatten_kernel, grid, block, 0, s, planes, pstep, pfs, (const int32_t *)work, ids, istep, ifs,
+                       ncomp, w, h, npx);
+}
+
+int kernel_count() { return 12; }
+
+}  // namespace cart_amd

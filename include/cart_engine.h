@@ -1,0 +1,154 @@
+/*
+ * cart_engine.h -- C ABI of the MI355X (gfx950) dense-stereo engine.
+ *
+ * This is the drop-in boundary for CART-SLAM's per-frame stereo hot path.  Every
+ * entry point names the reference interface it replaces (paths relative to the
+ * LorgeN/CART-SLAM tree).  Conventions:
+ *   - plain C types and one opaque handle; no C++/torch/OpenCV types;
+ *   - image pointers are DEVICE pointers, row-pitched (`*_step` in BYTES, like
+ *     cv::cuda::GpuMat::step); the caller owns every image buffer, the engine owns
+ *     only its workspaces (census maps, cost slabs, WTA maps) sized at create time;
+ *   - every call returns 0 on success, non-zero on failure, never throws and never
+ *     exits (the reference's CUDA_SAFE_CALL -> exit(), include/utils/cuda.cuh:193-201,
+ *     is deliberately NOT replicated); cart_last_error() gives the message;
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  The module adapter synchronises to mimic
+ *     cv::cuda::Stream::waitForCompletion() (src/modules/disparity/disparity.cu:77);
+ *   - thread-safe: one engine may be entered concurrently from many host threads
+ *     (the reference enters one module object for up to 12 frames at once,
+ *     include/cartslam.hpp:4-5); each call leases `n_frames` workspace slots.
+ */
+#ifndef CART_ENGINE_H
+#define CART_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CART_DISPARITY_INVALID (-32768) /* include/modules/disparity.hpp:17 */
+
+/* include/modules/planeseg.hpp:37-41 */
+enum { CART_PLANE_HORIZONTAL = 0, CART_PLANE_VERTICAL = 1, CART_PLANE_UNKNOWN = 2 };
+
+typedef struct cart_engine cart_engine;
+
+/* Constructor arguments of cart::ImageDisparityModule (include/modules/disparity.hpp:26-34,
+ * JSON keys src/cartconfig.cpp:144-152) plus the cv::cuda::createStereoSGM parameters the
+ * reference leaves at OpenCV's defaults (P1, P2, mode -> paths). */
+typedef struct {
+    int device_id;
+    int width, height;        /* DataSource::getImageSize(), include/datasource.hpp:75 */
+    int min_disparity;        /* "min_disparity", default 4; 0..64 supported */
+    int num_disparities;      /* "num_disparities": 64 | 128 | 256 */
+    int paths;                /* 4 (MODE_HH4) | 8 (MODE_HH) */
+    int p1, p2;               /* 10, 120 ; 31 + p2 must fit u8 */
+    int uniqueness_ratio;     /* disparity.hpp:32 -> 12 */
+    int smoothing_radius;     /* "smoothing_radius", default -1 (off); <= 8 */
+    int smoothing_iterations; /* "smoothing_iterations", default 5 */
+    int max_inflight;         /* workspace slots = frames that may be in flight / batched */
+} cart_engine_params;
+
+/* include/modules/planeseg.hpp:25-34 (PlaneParameters) */
+typedef struct {
+    int horizontal_min, horizontal_max; /* horizontalRange.first / .second */
+    int vertical_min, vertical_max;     /* verticalRange.first / .second */
+    int horizontal_center, vertical_center;
+} cart_plane_params;
+
+/* Fills *p with the reference's defaults (cartconfig.cpp:144-152, disparity.hpp:26-34). */
+void cart_engine_default_params(cart_engine_params *p);
+
+/* replaces: ImageDisparityModule ctor + cv::cuda::createStereoSGM (disparity.hpp:26-34) */
+int cart_engine_create(const cart_engine_params *params, cart_engine **out);
+void cart_engine_destroy(cart_engine *engine);
+
+/* Message of the last failed call made by THIS thread on `engine` (or of a failed
+ * create when engine == NULL).  Never NULL. */
+const char *cart_last_error(const cart_engine *engine);
+
+/* replaces: ImageDisparityModule::runInternal (src/modules/disparity/disparity.cu:49-80):
+ * cvtColor x2 (:66-67) -> StereoSGM::compute (:71) -> disparity::interpolate (:73-75,
+ * src/modules/disparity/interpolation.cu:85-99).  channels = 1 (gray) or 3 (BGR8).
+ * out: CV_16SC1-shaped, disparity x16, invalid pixels as the reference produces them. */
+int cart_compute_disparity(cart_engine *engine, const uint8_t *left, size_t left_step,
+                           const uint8_t *right, size_t right_step, int channels,
+                           int16_t *out, size_t out_step, void *stream);
+
+/* Batched-frame mode (north-star config 5): frame f of each array starts at
+ * base + f * <frame_stride> BYTES.  n_frames <= max_inflight. */
+int cart_compute_disparity_batch(cart_engine *engine, int n_frames,
+                                 const uint8_t *left, size_t left_step, size_t left_frame_stride,
+                                 const uint8_t *right, size_t right_step, size_t right_frame_stride,
+                                 int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
+                                 void *stream);
+
+/* replaces: cart::disparity::interpolate (interpolation.cu:85-99) on its own; in place like the
+ * reference's (the engine double-buffers internally).  min_disp16 / max_disp as disparity.hpp:27-28. */
+int cart_interpolate(cart_engine *engine, int n_frames, int16_t *disp, size_t step, size_t frame_stride,
+                     int radius, int iterations, int min_disp16, int max_disp, void *stream);
+
+/* replaces: ImageDisparityDerivativeModule::runInternal (src/modules/disparity/derivative.cu:151-184):
+ * out = CV_16SC2-shaped (ch0 vertical, ch1 horizontal), hist = 1x256 CV_32SC2-shaped device
+ * buffer (512 int32 per frame), overwritten. */
+int cart_disparity_derivative(cart_engine *engine, int n_frames,
+                              const int16_t *disp, size_t disp_step, size_t disp_frame_stride,
+                              int16_t *out, size_t out_step, size_t out_frame_stride,
+                              int32_t *hist512, void *stream);
+
+/* replaces: calculateDerivatives + mergeHistogram (src/modules/planeseg/planeseg.cu:31-158, launch :282-283).
+ * hist256 (device) is ADDED to: with hist_frame_stride_elems == 0 all frames accumulate into one
+ * persistent histogram like the module's (planeseg.hpp:160-161); with 256 each frame gets its own. */
+int cart_plane_derivative_hist(cart_engine *engine, int n_frames,
+                               const int16_t *disp, size_t disp_step, size_t disp_frame_stride,
+                               int16_t *out, size_t out_step, size_t out_frame_stride,
+                               int32_t *hist256, size_t hist_frame_stride_elems, void *stream);
+
+/* replaces: classifyPlanes, non-temporal (planeseg.cu:160-198, launch :349-350).
+ * params: one entry per frame if params_per_frame != 0, else params[0] for all. */
+int cart_plane_classify(cart_engine *engine, int n_frames,
+                        const int16_t *deriv, size_t deriv_step, size_t deriv_frame_stride,
+                        const cart_plane_params *params, int params_per_frame,
+                        uint8_t *planes, size_t planes_step, size_t planes_frame_stride, void *stream);
+
+/* New stage (no reference counterpart; BASELINE config 3 "plane CCL"): 4-connected components of
+ * the label map over labels {0,1}; id = smallest linear index y*width+x of the component,
+ * UNKNOWN pixels -> -1.  n_components (device, one int32 per frame) may be NULL. */
+int cart_plane_ccl(cart_engine *engine, int n_frames,
+                   const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
+                   int32_t *ids, size_t ids_step, size_t ids_frame_stride,
+                   int32_t *n_components, void *stream);
+
+/* replaces: HistogramPeakPlaneParameterProvider::updatePlaneParameters (planeseg.cu:405-458) +
+ * util::findPeaks (src/utils/peaks.cpp:12-72).  HOST function on a host histogram.  Returns 1 if
+ * *inout was updated, 0 on the reference's early-outs (parameters kept), <0 on error. */
+int cart_find_plane_params(const int32_t hist256[256], cart_plane_params *inout);
+
+/* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
+int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
+
+/* Test/diagnostic access to the workspace of the most recent compute call of the calling thread's
+ * lease (synchronises the device).  `what`: */
+enum {
+    CART_DBG_GRAY_L = 0, CART_DBG_GRAY_R = 1,     /* u8  [h][w]              */
+    CART_DBG_CENSUS_L = 2, CART_DBG_CENSUS_R = 3, /* u32 [h][w]              */
+    CART_DBG_PATH0 = 16,                          /* +r: u8 [h][w][D], r<paths */
+    CART_DBG_WTA_L = 32, CART_DBG_WTA_R = 33      /* u16 [h][w]              */
+};
+int cart_debug_read(cart_engine *engine, int frame_slot, int what, void *host_dst, size_t bytes);
+
+/* Device-time of the stages of the last compute call on this thread (ms, hipEvents); names are
+ * static strings. Returns the number of entries written (<= cap). Only valid when
+ * cart_engine_set_timing(engine, 1) was called before. */
+int cart_engine_set_timing(cart_engine *engine, int enabled);
+int cart_engine_last_timing(cart_engine *engine, const char **names, float *ms, int cap);
+
+/* Library / build identification ("cart_engine gfx950 <n kernels>"). */
+const char *cart_engine_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

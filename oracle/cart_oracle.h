@@ -1,0 +1,142 @@
+/*
+ * cart_oracle.h -- CPU restatement of CART-SLAM's dense-stereo hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing outside tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may include, link or call this library; the
+ * product path (cart-slam_amd/) never routes through it.
+ *
+ * PARITY UNPINNED.  The reference (LorgeN/CART-SLAM) ships no tests, golden
+ * vectors or fixtures for this path, cannot be built here (CUDA + OpenCV-CUDA
+ * + Boost + log4cxx, none installed) and delegates the SGM core to the
+ * un-vendored, un-pinned third-party module opencv_contrib `cudastereo`
+ * (cv::cuda::StereoSGM; call sites include/modules/disparity.hpp:31-33 and
+ * src/modules/disparity/disparity.cu:66-71, `find_package(OpenCV REQUIRED)`
+ * CMakeLists.txt:19).  This file therefore restates
+ *   (a) the published SGM / libSGM algorithm as used by that module, with every
+ *       choice the upstream text leaves open written down below as THE spec,
+ *   (b) the reference's own post-SGM kernels under clean "intent" semantics
+ *       (no tile row-shift, no in-place races).
+ *
+ * SPEC DECISIONS (each is a build-owned definition):
+ *  S1 gray      = (1868*B + 9617*G + 4899*R + 8192) >> 14      (OpenCV 8-bit BGR2GRAY)
+ *  S2 census    = 9x7 symmetric, 31 bits: for dy=-3..-1, dx=-4..4 then dy=0,
+ *                 dx=-4..-1 append bit I(y+dy,x+dx) > I(y-dy,x-dx) (MSB first).
+ *                 Pixels within 4 columns / 3 rows of the border get feature 0.
+ *  S3 cost      C(x,y,d) = popcount(cenL(x,y) ^ cenR(x-d-min_disp,y)); the right
+ *                 feature is 0 when x-d-min_disp is outside [0,W).
+ *  S4 path      L_r(p,d) = C(p,d) + min(L_r(q,d), L_r(q,d-1)+P1, L_r(q,d+1)+P1,
+ *                 m+P2) - m, q = p-r, m = min_k L_r(q,k); a path starts at the
+ *                 first in-image pixel with the recurrence state all-zero
+ *                 (=> L = C there).  d-1 / d+1 outside [0,D) do not take part.
+ *                 Stored as u8 (values <= 31+P2; P2 <= 224 required).
+ *                 4 paths = {down, up, right, left}; 8 paths add the 4 diagonals.
+ *  S5 WTA left  S = sum_r L_r; best = min over d of (S<<16 | d)  (ties -> lowest d);
+ *                 unique iff for every d: (float)S[d]*u >= (float)S[best] or
+ *                 |d-best| <= 1, u = (float)(100-uniqueness_ratio)/100.0f;
+ *                 not unique -> 0xFFFF.  Sub-pixel (x16): if 0<best<D-1,
+ *                 num = S[b-1]-S[b+1], den = S[b-1]-2S[b]+S[b+1],
+ *                 disp = 16*b + (den ? (16*num+den)/(2*den) : 0)  (C truncation).
+ *  S6 WTA right R(p) = argmin_d S(p+d, d) over d with p+d < W, ties -> lowest d,
+ *                 integer disparity (not x16), never invalid.
+ *  S7 median    3x3 on both maps as u16 (0xFFFF sorts highest); the one-pixel
+ *                 image border passes through unfiltered.
+ *  S8 LR check  left pixel -> 0xFFFF if gray_left==0, or already 0xFFFF, or
+ *                 k = x-(dL>>4) in [0,W) and |R(k)-(dL>>4)| > 1.
+ *  S9 range     0xFFFF -> (min_disp-1)*16, else += min_disp*16; stored s16.
+ *  S10 post stages: Jacobi reads of the unmodified input, out-of-image samples
+ *                 skipped by window means and making a difference INVALID.
+ *  S11 findPeaks: index sort is by descending value, ties by ascending index
+ *                 (the reference's std::sort leaves tie order unspecified);
+ *                 peaks sorted by descending persistence, ties by birth order.
+ *  S12 CCL      (no reference counterpart) 4-connected components over the plane
+ *                 label map for labels {0,1}; component id = smallest linear index
+ *                 y*W+x in the component; label-2 (UNKNOWN) pixels get -1.
+ */
+#ifndef CART_ORACLE_H
+#define CART_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CART_ORACLE_INVALID (-32768)      /* include/modules/disparity.hpp:17 */
+#define CART_ORACLE_WTA_INVALID 0xFFFFu
+
+typedef struct {
+    int width, height;
+    int min_disparity;      /* cartconfig.cpp:147 default 4 */
+    int num_disparities;    /* 64 | 128 | 256 */
+    int paths;              /* 4 | 8 */
+    int p1, p2;             /* 10, 120 */
+    int uniqueness_ratio;   /* disparity.hpp:32 -> 12 */
+} cart_oracle_sgm_params;
+
+/* include/modules/planeseg.hpp:25-34 */
+typedef struct {
+    int horizontal_min, horizontal_max;
+    int vertical_min, vertical_max;
+    int horizontal_center, vertical_center;
+} cart_oracle_plane_params;
+
+/* S1; src pitched BGR (src_step bytes/row), dst tight w*h. disparity.cu:66-67 */
+void cart_oracle_bgr2gray(const uint8_t *bgr, size_t src_step, int w, int h, uint8_t *gray);
+
+/* S2; gray tight, census tight u32. */
+void cart_oracle_census9x7(const uint8_t *gray, int w, int h, uint32_t *census);
+
+/* S3+S4 for one direction (dx,dy in {-1,0,1}); L is [h][w][D] u8. */
+void cart_oracle_aggregate_path(const uint32_t *cen_l, const uint32_t *cen_r, int w, int h, int D,
+                                int min_disp, int p1, int p2, int dx, int dy, uint8_t *L);
+
+/* direction table used for `paths` = 4 or 8: index -> (dx,dy). */
+void cart_oracle_path_dir(int index, int *dx, int *dy);
+
+/* S5+S6 on a summed volume S [h][w][D] u16. */
+void cart_oracle_wta(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
+                     uint16_t *left, uint16_t *right);
+
+/* S7 */
+void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst);
+
+/* S8+S9: left_med/right_med are the median-filtered WTA maps. */
+void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
+                                int w, int h, int min_disp, int16_t *out);
+
+/* Whole SGM core (a-4): gray L/R tight -> s16 disparity x16.  If S_out is
+ * non-NULL it receives the summed volume [h][w][D] u16. Returns 0 / -1. */
+int cart_oracle_sgm(const cart_oracle_sgm_params *p, const uint8_t *gray_l, const uint8_t *gray_r,
+                    int16_t *disp, uint16_t *S_out);
+
+/* a-5 interpolation.cu:17-82 under S10; min_disp16 = cfg*16, max_disp = image width
+ * (disparity.hpp:27-28 quirk). in/out tight s16; out may not alias in. */
+void cart_oracle_interpolate(const int16_t *in, int w, int h, int radius, int iterations,
+                             int min_disp16, int max_disp, int16_t *out);
+
+/* a-7 derivative.cu:27-116: out is [h][w][2] (ch0 vertical, ch1 horizontal),
+ * hist is [256][2] (interleaved like CV_32SC2 1x256), overwritten. */
+void cart_oracle_directional_derivative(const int16_t *disp, int w, int h, int16_t *out, int32_t *hist);
+
+/* a-8 planeseg.cu:31-158: out tight s16, hist256 is ADDED to (persistent). */
+void cart_oracle_plane_derivative(const int16_t *disp, int w, int h, int16_t *out, int32_t *hist256);
+
+/* a-9 peaks.cpp:12-72 (S11): returns number of peaks; born/died/left/right
+ * arrays must hold n entries each, sorted by persistence. */
+int cart_oracle_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
+
+/* a-9 planeseg.cu:405-458: updates *params in place; returns 1 if updated, 0 on
+ * the reference's early-outs (previous parameters kept). */
+int cart_oracle_histogram_peak_params(const int32_t *hist256, cart_oracle_plane_params *params);
+
+/* a-10 planeseg.cu:160-198 (non-temporal). */
+void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_plane_params *params, uint8_t *planes);
+
+/* a-11 (S12). Returns the number of components. */
+int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,257 @@
+"""Second, independent restatement of the hot path in numpy / pure Python (small images only).
+
+Used only to cross-check the C oracle (oracle/cart_oracle.c): it is written from the spec in
+oracle/cart_oracle.h (S1..S12), not from the C code -- array shifts and per-pixel numpy ops
+instead of scan-line walkers -- so a transcription slip in either shows up as a mismatch.
+"""
+import numpy as np
+
+INVALID = -32768
+
+
+def bgr2gray(bgr):
+    b, g, r = (bgr[..., i].astype(np.uint32) for i in range(3))
+    return ((1868 * b + 9617 * g + 4899 * r + 8192) >> 14).astype(np.uint8)
+
+
+def census(gray):
+    h, w = gray.shape
+    g = gray.astype(np.int32)
+    pad = np.zeros((h + 6, w + 8), np.int32)
+    pad[3:-3, 4:-4] = g
+
+    def sh(dy, dx):
+        return pad[3 + dy:3 + dy + h, 4 + dx:4 + dx + w]
+
+    f = np.zeros((h, w), np.uint32)
+    pairs = [(dy, dx) for dy in (-3, -2, -1) for dx in range(-4, 5)] + [(0, dx) for dx in range(-4, 0)]
+    assert len(pairs) == 31
+    for dy, dx in pairs:
+        f = (f << np.uint32(1)) | (sh(dy, dx) > sh(-dy, -dx)).astype(np.uint32)
+    inner = np.zeros((h, w), bool)
+    inner[3:h - 3, 4:w - 4] = True
+    return np.where(inner, f, 0).astype(np.uint32)
+
+
+def cost_volume(cl, cr, D, min_disp):
+    h, w = cl.shape
+    C = np.empty((h, w, D), np.int32)
+    xs = np.arange(w)
+    for d in range(D):
+        xr = xs - d - min_disp
+        ok = (xr >= 0) & (xr < w)
+        fr = np.where(ok[None, :], cr[:, np.clip(xr, 0, w - 1)], 0).astype(np.uint32)
+        x = cl ^ fr
+        C[:, :, d] = np.array([bin(int(v)).count("1") for v in x.ravel()], np.int32).reshape(h, w)
+    return C
+
+
+def aggregate(C, dx, dy, p1, p2):
+    h, w, D = C.shape
+    L = np.zeros((h, w, D), np.int32)
+    ys = range(h) if dy >= 0 else range(h - 1, -1, -1)
+    xs = range(w) if dx >= 0 else range(w - 1, -1, -1)
+    big = 1 << 20
+    for y in ys:
+        for x in xs:
+            py, px = y - dy, x - dx
+            if 0 <= py < h and 0 <= px < w:
+                prev = L[py, px]
+            else:
+                prev = np.zeros(D, np.int32)
+            m = prev.min()
+            lo = np.concatenate(([big], prev[:-1])) + p1
+            hi = np.concatenate((prev[1:], [big])) + p1
+            best = np.minimum(np.minimum(prev, lo), np.minimum(hi, m + p2))
+            L[y, x] = C[y, x] + best - m
+    return L
+
+
+DIRS = [(0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (-1, 1), (-1, -1), (1, -1)]
+
+
+def wta(S, uniqueness_ratio):
+    h, w, D = S.shape
+    u = np.float32(100 - uniqueness_ratio) / np.float32(100.0)
+    left = np.empty((h, w), np.uint16)
+    right = np.empty((h, w), np.uint16)
+    for y in range(h):
+        for x in range(w):
+            s = S[y, x].astype(np.int64)
+            bd = int(np.argmin(s))  # first minimum
+            bc = int(s[bd])
+            lhs = s.astype(np.float32) * u
+            ok = (lhs >= np.float32(bc)) | (np.abs(np.arange(D) - bd) <= 1)
+            if not ok.all():
+                left[y, x] = 0xFFFF
+                continue
+            sub = bd * 16
+            if 0 < bd < D - 1:
+                num = int(s[bd - 1] - s[bd + 1]); den = int(s[bd - 1] - 2 * bc + s[bd + 1])
+                if den != 0:
+                    q = num * 16 + den
+                    sub += int(abs(q) // (2 * den)) * (1 if q >= 0 else -1)  # C truncation (den > 0)
+            left[y, x] = sub & 0xFFFF
+        for p in range(w):
+            n = min(D, w - p)
+            diag = np.array([S[y, p + d, d] for d in range(n)], np.int64)
+            right[y, p] = int(np.argmin(diag))
+    return left, right
+
+
+def median3x3(a):
+    h, w = a.shape
+    out = a.copy()
+    if h >= 3 and w >= 3:
+        st = np.stack([a[1 + dy:h - 1 + dy, 1 + dx:w - 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
+        out[1:-1, 1:-1] = np.sort(st, axis=0)[4]
+    return out
+
+
+def lr_check_range(lm, rm, gray, min_disp):
+    h, w = lm.shape
+    out = np.empty((h, w), np.int16)
+    for y in range(h):
+        for x in range(w):
+            org = int(lm[y, x])
+            bad = gray[y, x] == 0 or org == 0xFFFF
+            if not bad:
+                d = org >> 4
+                k = x - d
+                if 0 <= k < w and abs(int(rm[y, k]) - d) > 1:
+                    bad = True
+            out[y, x] = (min_disp - 1) * 16 if bad else org + min_disp * 16
+    return out
+
+
+def sgm(gl, gr, D, paths, min_disp=4, p1=10, p2=120, uniq=12):
+    cl, cr = census(gl), census(gr)
+    C = cost_volume(cl, cr, D, min_disp)
+    S = np.zeros(C.shape, np.int64)
+    Ls = []
+    for dx, dy in DIRS[:paths]:
+        L = aggregate(C, dx, dy, p1, p2)
+        Ls.append(L)
+        S += L
+    wl, wr = wta(S, uniq)
+    disp = lr_check_range(median3x3(wl), median3x3(wr), gl, min_disp)
+    return dict(census_l=cl, census_r=cr, paths=Ls, S=S, wta_l=wl, wta_r=wr, disp=disp)
+
+
+def interpolate(disp, radius, iterations, min16, maxd):
+    h, w = disp.shape
+    a = disp.astype(np.int64)
+    for _ in range(iterations):
+        b = np.empty_like(a)
+        for y in range(h):
+            for x in range(w):
+                win = a[max(0, y - radius + 1):min(h, y + radius), max(0, x - radius + 1):min(w, x + radius)]
+                v = win[(win > min16) & (win < maxd)]
+                b[y, x] = int(v.sum()) // v.size if v.size > radius * radius + 1 else INVALID
+        a = b
+    return a.astype(np.int16)
+
+
+def _wrap16(v):
+    return ((np.asarray(v, np.int64) + 32768) % 65536 - 32768)
+
+
+def directional_derivative(disp):
+    h, w = disp.shape
+    d = disp.astype(np.int64)
+    out = np.full((h, w, 2), INVALID, np.int64)
+    hist = np.zeros((256, 2), np.int64)
+    for y in range(h):
+        for x in range(w):
+            if 2 <= y < h - 2 and d[y + 2, x] != INVALID and d[y - 2, x] != INVALID:
+                v = int(_wrap16(d[y + 2, x] - d[y - 2, x])); out[y, x, 0] = v
+                if -128 <= v <= 127: hist[v + 128, 0] += 1
+            if 2 <= x < w - 2 and d[y, x + 2] != INVALID and d[y, x - 2] != INVALID:
+                v = int(_wrap16(d[y, x + 2] - d[y, x - 2])); out[y, x, 1] = v
+                if -128 <= v <= 127: hist[v + 128, 1] += 1
+    return out.astype(np.int16), hist.astype(np.int32)
+
+
+def plane_derivative(disp):
+    h, w = disp.shape
+    d = disp.astype(np.int64)
+    lp = np.full((h, w), INVALID, np.int64)
+    for y in range(h):
+        for x in range(w):
+            col = d[max(0, y - 2):min(h, y + 3), x]
+            v = col[col != INVALID]
+            if v.size:
+                s = int(_wrap16(v.sum()))  # sequential s16 wrap == wrap of the total
+                q = abs(s) // v.size
+                lp[y, x] = q if s >= 0 else -q
+    out = np.full((h, w), INVALID, np.int64)
+    hist = np.zeros(256, np.int64)
+    for y in range(1, h - 1):
+        for x in range(w):
+            if lp[y - 1, x] != INVALID and lp[y, x] != INVALID and lp[y + 1, x] != INVALID:
+                v = int(_wrap16(lp[y + 1, x] - lp[y - 1, x])); out[y, x] = v
+                if -128 <= v <= 127: hist[v + 128] += 1
+    return out.astype(np.int16), hist.astype(np.int32)
+
+
+def classify(deriv, params):
+    hmin, hmax, vmin, vmax = params[:4]
+    d = deriv.astype(np.int64)
+    ok = d != INVALID
+    out = np.full(d.shape, 2, np.uint8)
+    isv = ok & (d >= vmin) & (d < vmax)
+    ish = ok & (d >= hmin) & (d < hmax)
+    out[isv] = 1
+    out[ish] = 0  # horizontal test comes first in the reference (planeseg.cu:191-195)
+    return out
+
+
+def ccl(planes):
+    """flood fill; id = min linear index."""
+    h, w = planes.shape
+    ids = np.full((h, w), -1, np.int32)
+    seen = np.zeros((h, w), bool)
+    n = 0
+    for y in range(h):
+        for x in range(w):
+            if planes[y, x] > 1 or seen[y, x]:
+                continue
+            n += 1
+            c = planes[y, x]; root = y * w + x
+            stack = [(y, x)]; seen[y, x] = True
+            while stack:
+                cy, cx = stack.pop()
+                ids[cy, cx] = root
+                for ny, nx in ((cy - 1, cx), (cy + 1, cx), (cy, cx - 1), (cy, cx + 1)):
+                    if 0 <= ny < h and 0 <= nx < w and not seen[ny, nx] and planes[ny, nx] == c:
+                        seen[ny, nx] = True; stack.append((ny, nx))
+    return ids, n
+
+
+def find_peaks(data):
+    """0-dim persistent homology of a 1-D signal (watershed from the top), spec S11."""
+    data = [int(v) for v in data]
+    n = len(data)
+    order = sorted(range(n), key=lambda i: (-data[i], i))
+    comp = [-1] * n
+    peaks = []  # dicts
+    for idx in order:
+        l = comp[idx - 1] if idx > 0 else -1
+        r = comp[idx + 1] if idx < n - 1 else -1
+        if l < 0 and r < 0:
+            peaks.append(dict(born=idx, left=idx, right=idx, died=-1)); comp[idx] = len(peaks) - 1
+        elif l >= 0 and r < 0:
+            peaks[l]["right"] += 1; comp[idx] = l
+        elif l < 0 and r >= 0:
+            peaks[r]["left"] -= 1; comp[idx] = r
+        else:
+            if data[peaks[l]["born"]] > data[peaks[r]["born"]]:
+                peaks[r]["died"] = idx; peaks[l]["right"] = peaks[r]["right"]
+                comp[peaks[l]["right"]] = comp[idx] = l
+            else:
+                peaks[l]["died"] = idx; peaks[r]["left"] = peaks[l]["left"]
+                comp[peaks[r]["left"]] = comp[idx] = r
+    def pers(p):
+        return (1 << 31) - 1 if p["died"] < 0 else data[p["born"]] - data[p["died"]]
+    peaks.sort(key=lambda p: -pers(p))  # python's sort is stable
+    return [(p["born"], p["died"], p["left"], p["right"]) for p in peaks]

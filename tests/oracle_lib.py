@@ -1,0 +1,181 @@
+"""ctypes wrapper around oracle/_build/libcart_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libcart_oracle.so")
+
+
+class SgmParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "min_disparity", "num_disparities", "paths", "p1", "p2",
+                                       "uniqueness_ratio")]
+
+
+class PlaneParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("horizontal_min", "horizontal_max", "vertical_min", "vertical_max",
+                                       "horizontal_center", "vertical_center")]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+_lib = None
+
+
+def build():
+    src_time = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("cart_oracle.c", "cart_oracle.h"))
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < src_time:
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.cart_oracle_sgm.restype = C.c_int
+        _lib.cart_oracle_find_peaks.restype = C.c_int
+        _lib.cart_oracle_histogram_peak_params.restype = C.c_int
+        _lib.cart_oracle_ccl.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def bgr2gray(bgr):
+    h, w, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty((h, w), np.uint8)
+    lib().cart_oracle_bgr2gray(_p(bgr), C.c_size_t(w * 3), w, h, _p(out))
+    return out
+
+
+def census(gray):
+    h, w = gray.shape
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = np.empty((h, w), np.uint32)
+    lib().cart_oracle_census9x7(_p(gray), w, h, _p(out))
+    return out
+
+
+def path_dir(i):
+    dx, dy = C.c_int(), C.c_int()
+    lib().cart_oracle_path_dir(i, C.byref(dx), C.byref(dy))
+    return dx.value, dy.value
+
+
+def aggregate_path(cl, cr, D, min_disp, p1, p2, dx, dy):
+    h, w = cl.shape
+    L = np.empty((h, w, D), np.uint8)
+    lib().cart_oracle_aggregate_path(_p(np.ascontiguousarray(cl)), _p(np.ascontiguousarray(cr)), w, h, D, min_disp, p1, p2,
+                                     dx, dy, _p(L))
+    return L
+
+
+def wta(S, uniqueness_ratio):
+    h, w, D = S.shape
+    S = np.ascontiguousarray(S, np.uint16)
+    l = np.empty((h, w), np.uint16); r = np.empty((h, w), np.uint16)
+    lib().cart_oracle_wta(_p(S), w, h, D, uniqueness_ratio, _p(l), _p(r))
+    return l, r
+
+
+def median3x3(a):
+    h, w = a.shape
+    a = np.ascontiguousarray(a, np.uint16)
+    o = np.empty_like(a)
+    lib().cart_oracle_median3x3_u16(_p(a), w, h, _p(o))
+    return o
+
+
+def lr_check_range(lm, rm, gray, min_disp):
+    h, w = lm.shape
+    o = np.empty((h, w), np.int16)
+    lib().cart_oracle_lr_check_range(_p(np.ascontiguousarray(lm, np.uint16)), _p(np.ascontiguousarray(rm, np.uint16)),
+                                     _p(np.ascontiguousarray(gray, np.uint8)), w, h, min_disp, _p(o))
+    return o
+
+
+def sgm(gl, gr, D, paths, min_disp=4, p1=10, p2=120, uniq=12, want_S=False):
+    h, w = gl.shape
+    p = SgmParams(w, h, min_disp, D, paths, p1, p2, uniq)
+    disp = np.empty((h, w), np.int16)
+    S = np.empty((h, w, D), np.uint16) if want_S else None
+    rc = lib().cart_oracle_sgm(C.byref(p), _p(np.ascontiguousarray(gl, np.uint8)), _p(np.ascontiguousarray(gr, np.uint8)),
+                               _p(disp), _p(S) if want_S else None)
+    assert rc == 0, "cart_oracle_sgm failed"
+    return (disp, S) if want_S else disp
+
+
+def interpolate(disp, radius, iterations, min_disp16, max_disp):
+    h, w = disp.shape
+    o = np.empty((h, w), np.int16)
+    lib().cart_oracle_interpolate(_p(np.ascontiguousarray(disp, np.int16)), w, h, radius, iterations, min_disp16, max_disp, _p(o))
+    return o
+
+
+def disparity_module(left, right, D, paths, min_disp=4, p1=10, p2=120, uniq=12, radius=-1, iterations=5):
+    """Whole ImageDisparityModule::runInternal (disparity.cu:49-80) on host arrays."""
+    if left.ndim == 3:
+        left, right = bgr2gray(left), bgr2gray(right)
+    d = sgm(left, right, D, paths, min_disp, p1, p2, uniq)
+    if radius > 0 and iterations > 0:
+        d = interpolate(d, radius, iterations, min_disp * 16, left.shape[1])
+    return d
+
+
+def directional_derivative(disp):
+    h, w = disp.shape
+    o = np.empty((h, w, 2), np.int16); hist = np.empty((256, 2), np.int32)
+    lib().cart_oracle_directional_derivative(_p(np.ascontiguousarray(disp, np.int16)), w, h, _p(o), _p(hist))
+    return o, hist
+
+
+def plane_derivative(disp, hist=None):
+    h, w = disp.shape
+    o = np.empty((h, w), np.int16)
+    if hist is None:
+        hist = np.zeros(256, np.int32)
+    assert hist.dtype == np.int32 and hist.flags.c_contiguous
+    lib().cart_oracle_plane_derivative(_p(np.ascontiguousarray(disp, np.int16)), w, h, _p(o), _p(hist))
+    return o, hist
+
+
+def find_peaks(data):
+    data = np.ascontiguousarray(data, np.int32)
+    n = data.size
+    arrs = [np.empty(n, np.int32) for _ in range(4)]
+    k = lib().cart_oracle_find_peaks(_p(data), n, *[_p(a) for a in arrs])
+    return [tuple(int(a[i]) for a in arrs) for i in range(k)]
+
+
+def histogram_peak_params(hist, params=None):
+    hist = np.ascontiguousarray(hist, np.int32)
+    p = PlaneParams(*(params or (0,) * 6))
+    rc = lib().cart_oracle_histogram_peak_params(_p(hist), C.byref(p))
+    return bool(rc), p.as_tuple()
+
+
+def classify(deriv, params):
+    h, w = deriv.shape
+    p = PlaneParams(*params)
+    o = np.empty((h, w), np.uint8)
+    lib().cart_oracle_classify(_p(np.ascontiguousarray(deriv, np.int16)), w, h, C.byref(p), _p(o))
+    return o
+
+
+def ccl(planes):
+    h, w = planes.shape
+    ids = np.empty((h, w), np.int32)
+    n = lib().cart_oracle_ccl(_p(np.ascontiguousarray(planes, np.uint8)), w, h, _p(ids))
+    return ids, n

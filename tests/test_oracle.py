@@ -1,0 +1,181 @@
+"""CPU tests: the C oracle against (a) the independent numpy restatement, (b) hand-computed
+known answers, (c) the committed golden fixtures.  PARITY UNPINNED: the reference holds no
+fixtures for this path; the golden files are produced by tests/golden/make_golden.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import np_ref as N
+import oracle_lib as O
+from cartslam import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rand_disp(rng, h, w, lo=64, hi=1200, p_invalid=0.2):
+    d = rng.integers(lo, hi, (h, w)).astype(np.int16)
+    d[rng.random((h, w)) < p_invalid] = -32768
+    return d
+
+
+def test_gray_known_answers():
+    bgr = np.array([[[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]]], np.uint8)
+    g = O.bgr2gray(bgr)[0]
+    # (1868*B + 9617*G + 4899*R + 8192) >> 14
+    assert list(g) == [0, 255, 29, 150, 76, (1868 * 10 + 9617 * 200 + 4899 * 77 + 8192) >> 14]
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (9, 13, 3)).astype(np.uint8)
+    assert (O.bgr2gray(x) == N.bgr2gray(x)).all()
+
+
+def test_census_known_answers():
+    # horizontal ramp: every pair with dx<0 compares darker-left > brighter-right = 0, dx>0 -> 1
+    g = np.tile(np.arange(20, dtype=np.uint8) * 5, (12, 1))
+    c = O.census(g)
+    assert (c[:3] == 0).all() and (c[-3:] == 0).all() and (c[:, :4] == 0).all() and (c[:, -4:] == 0).all()
+    bits = []
+    for dy in (-3, -2, -1):
+        bits += [1 if dx > 0 else 0 for dx in range(-4, 5)]
+    bits += [0] * 4
+    expect = int("".join(map(str, bits)), 2)
+    assert (c[3:-3, 4:-4] == expect).all()
+    assert (O.census(np.full((10, 12), 7, np.uint8)) == 0).all()
+
+
+@pytest.mark.parametrize("w,h,D,P,md", [(72, 40, 64, 8, 4), (80, 24, 64, 4, 0), (150, 20, 128, 8, 7)])
+def test_sgm_matches_numpy_restatement(w, h, D, P, md):
+    l, r, _ = synth.make_pair(w, h, D, md, seed=123 + w)
+    ref = N.sgm(l, r, D, P, md)
+    cl, cr = O.census(l), O.census(r)
+    assert (cl == ref["census_l"]).all() and (cr == ref["census_r"]).all()
+    for i in range(P):
+        dx, dy = O.path_dir(i)
+        assert (dx, dy) == N.DIRS[i]
+        assert (O.aggregate_path(cl, cr, D, md, 10, 120, dx, dy) == ref["paths"][i]).all(), f"path {i}"
+    d, S = O.sgm(l, r, D, P, md, want_S=True)
+    assert (S == ref["S"]).all()
+    wl, wr = O.wta(S, 12)
+    assert (wl == ref["wta_l"]).all() and (wr == ref["wta_r"]).all()
+    assert (d == ref["disp"]).all()
+
+
+def test_path_properties():
+    l, r, _ = synth.make_pair(96, 48, 64, 4, seed=5)
+    cl, cr = O.census(l), O.census(r)
+    C = N.cost_volume(cl, cr, 64, 4)
+    for i in range(8):
+        dx, dy = O.path_dir(i)
+        L = O.aggregate_path(cl, cr, 64, 4, 10, 120, dx, dy).astype(np.int32)
+        # path start == matching cost; everywhere C <= L <= C + P2
+        if dy > 0: assert (L[0] == C[0]).all()
+        if dy < 0: assert (L[-1] == C[-1]).all()
+        if dx > 0: assert (L[:, 0] == C[:, 0]).all()
+        if dx < 0: assert (L[:, -1] == C[:, -1]).all()
+        assert (L >= C).all() and (L <= C + 120).all() and L.max() <= 151
+    # P1 = P2 = 0 makes every path the plain cost plus nothing: L == C
+    L0 = O.aggregate_path(cl, cr, 64, 4, 0, 0, 1, 1)
+    assert (L0 == C).all()
+
+
+def test_wta_known_answers():
+    D = 64
+    S = np.full((1, 70, D), 500, np.uint16)
+    S[0, :, 10] = 100; S[0, :, 9] = 300; S[0, :, 11] = 200           # clean minimum, sub-pixel towards 11
+    S[0, 5, 40] = 105                                                 # a second, non-adjacent near-minimum -> not unique
+    S[0, 6, 11] = 100                                                 # adjacent tie -> unique, lowest d wins
+    S[0, 7, :] = 77                                                   # flat -> everything equal: 77*0.88 < 77 -> invalid
+    wl, wr = O.wta(S, 12)
+    num, den = 300 - 200, 300 - 200 + 200
+    assert wl[0, 0] == 10 * 16 + (num * 16 + den) // (2 * den)
+    assert wl[0, 5] == 0xFFFF and wl[0, 7] == 0xFFFF
+    assert wl[0, 6] == 10 * 16 + ((300 - 100) * 16 + (300 - 200 + 100)) // (2 * (300 - 200 + 100))
+    # right view: argmin_d S(p+d, d); column 10 is the minimum everywhere it exists
+    assert wr[0, 20] == 10 and wr[0, 59] == 10 and wr[0, 69] == 0
+    assert wr[0, 0] == 7  # S(7,7) = 77 on the flat pixel beats S(10,10) = 100
+    # uniqueness 0 -> u = 1.0: every candidate passes S*1.0 >= best, even the flat pixel (-> d = 0)
+    wl0, _ = O.wta(S, 0)
+    assert wl0[0, 5] != 0xFFFF and wl0[0, 7] == 0
+
+
+def test_median_and_lr_check():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 2000, (17, 23)).astype(np.uint16)
+    a[rng.random(a.shape) < 0.3] = 0xFFFF
+    assert (O.median3x3(a) == N.median3x3(a)).all()
+    lm = (rng.integers(0, 30, (9, 40)) * 16).astype(np.uint16); lm[2, 3] = 0xFFFF
+    rm = rng.integers(0, 30, (9, 40)).astype(np.uint16)
+    g = rng.integers(0, 3, (9, 40)).astype(np.uint8)
+    assert (O.lr_check_range(lm, rm, g, 4) == N.lr_check_range(lm, rm, g, 4)).all()
+    out = O.lr_check_range(lm, rm, np.zeros_like(g), 4)
+    assert (out == 48).all()  # gray==0 masks everything: (min_disp-1)*16
+
+
+@pytest.mark.parametrize("r,it", [(1, 1), (2, 1), (3, 2), (2, 5)])
+def test_interpolate(r, it):
+    rng = np.random.default_rng(r * 10 + it)
+    d = rand_disp(rng, 21, 37, 40, 400, 0.3)
+    assert (O.interpolate(d, r, it, 64, 300) == N.interpolate(d, r, it, 64, 300)).all()
+
+
+def test_derivatives_classify_ccl():
+    rng = np.random.default_rng(7)
+    d = rand_disp(rng, 33, 41, 64, 180, 0.15)
+    d[5, 5] = 32767; d[3, 5] = -32767  # forces s16 wrap in both derivative kernels
+    a, h = O.directional_derivative(d); a2, h2 = N.directional_derivative(d)
+    assert (a == a2).all() and (h == h2).all()
+    b, hb = O.plane_derivative(d); b2, hb2 = N.plane_derivative(d)
+    assert (b == b2).all() and (hb == hb2).all()
+    _, hb3 = O.plane_derivative(d, hb.copy())
+    assert (hb3 == 2 * hb).all()  # cumulative, planeseg.cu:157
+    params = (6, 18, -5, 6, 11, 0)
+    pl = O.classify(b, params)
+    assert (pl == N.classify(b, params)).all()
+    pl2 = rng.integers(0, 3, (25, 31)).astype(np.uint8)
+    ids, n = O.ccl(pl2); ids2, n2 = N.ccl(pl2)
+    assert (ids == ids2).all() and n == n2
+    assert (ids[pl2 == 2] == -1).all()
+
+
+def test_find_peaks_and_params():
+    rng = np.random.default_rng(11)
+    for k in range(30):
+        hh = rng.integers(0, 40, 256) if k % 2 else rng.integers(0, 5, 256) * rng.integers(0, 3000, 256)
+        assert O.find_peaks(hh.astype(np.int32)) == N.find_peaks(hh)
+    # two clean triangular peaks: at bin 128 (zero derivative) and bin 139
+    h = np.zeros(256, np.int32)
+    for i in range(-4, 5):
+        h[128 + i] = 1000 - 200 * abs(i)
+        h[139 + i] = max(h[139 + i], 600 - 120 * abs(i))
+    ok, p = O.histogram_peak_params(h)
+    pk = O.find_peaks(h)
+    assert pk[0][0] == 128 and pk[0][1] == -1 and pk[1][0] == 139
+    assert ok and p[5] == 0 and p[4] == 11
+    # valley = first strict minimum scanning 128..138
+    valley = 128 + int(np.argmin(h[128:139]))
+    assert p[3] == valley - 127 and p[0] == valley - 127
+    # early-outs keep the previous parameters
+    ok2, p2 = O.histogram_peak_params(np.zeros(256, np.int32), (1, 2, 3, 4, 5, 6))
+    assert not ok2 and p2 == (1, 2, 3, 4, 5, 6)
+
+
+def test_golden_fixtures():
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+    assert files, "no golden fixtures committed"
+    for f in files:
+        z = np.load(f)
+        cfg = {k: int(z[k]) for k in ("D", "P", "min_disp", "radius", "iterations")}
+        d = O.disparity_module(z["left"], z["right"], cfg["D"], cfg["P"], cfg["min_disp"], radius=cfg["radius"],
+                               iterations=cfg["iterations"])
+        assert (d == z["disparity"]).all(), f
+        dd, hist = O.plane_derivative(d)
+        assert (dd == z["plane_derivative"]).all() and (hist == z["plane_hist"]).all(), f
+        dir_d, dir_h = O.directional_derivative(d)
+        assert (dir_d == z["dir_derivative"]).all() and (dir_h == z["dir_hist"]).all(), f
+        ok, pp = O.histogram_peak_params(hist)
+        assert tuple(z["plane_params"]) == pp and bool(z["plane_params_ok"]) == ok, f
+        pl = O.classify(dd, pp)
+        assert (pl == z["planes"]).all(), f
+        ids, n = O.ccl(pl)
+        assert (ids == z["ccl_ids"]).all() and n == int(z["ccl_n"]), f
