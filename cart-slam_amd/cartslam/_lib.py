@@ -45,7 +45,7 @@ PROTOTYPES = {
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),
     "cart_engine_set_timing": (_i, [_vp, _i]),
-    "cart_engine_last_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
+    "cart_engine_collect_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cart_engine_version": (C.c_char_p, []),
 }
 

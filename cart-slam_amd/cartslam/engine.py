@@ -172,13 +172,15 @@ class Engine:
     def set_timing(self, enabled=True):
         self._check(self._lib.cart_engine_set_timing(self._h, 1 if enabled else 0), "cart_engine_set_timing")
 
-    def last_timing(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        n = self._lib.cart_engine_last_timing(self._h, names, ms, 16)
+    def collect_timing(self):
+        """-> ({stage: mean ms per call}, n_calls) over the calls recorded since set_timing(True)."""
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        calls = C.c_int(0)
+        n = self._lib.cart_engine_collect_timing(self._h, names, ms, 8, C.byref(calls))
         if n < 0:
-            raise EngineError("cart_engine_last_timing: " + self._lib.cart_last_error(self._h).decode())
-        return {names[i].decode(): float(ms[i]) for i in range(n)}
+            raise EngineError("cart_engine_collect_timing: " + self._lib.cart_last_error(self._h).decode())
+        return {names[i].decode(): float(ms[i]) for i in range(n)}, calls.value
 
 
 def find_plane_params(hist256, params=None):

@@ -38,7 +38,14 @@ struct Slot {
     bool used = false;
 };
 
-constexpr int kMaxTimings = 16;
+constexpr int kMaxTimings = 8;
+constexpr int kTimingRing = 256;
+
+struct TimingRec {
+    hipEvent_t ev[kMaxTimings + 1] = {};
+    const char *names[kMaxTimings] = {};
+    int n = 0;
+};
 
 }  // namespace
 
@@ -59,11 +66,8 @@ struct cart_engine {
     std::condition_variable cv;
     std::vector<Slot> slots;
     bool timing = false;
-    // timing of the last compute call (any thread; guarded by mu)
-    hipEvent_t tev[kMaxTimings + 1] = {};
-    const char *tnames[kMaxTimings] = {};
-    int ntimes = 0;
-    hipStream_t tstream = nullptr;
+    std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
+    size_t ring_calls = 0;
 };
 
 namespace {
@@ -224,8 +228,6 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
             cart_engine_destroy(e);
             return fail("hipEventCreate failed");
         }
-    for (auto &ev : e->tev)
-        if (hipEventCreate(&ev) != hipSuccess) { cart_engine_destroy(e); return fail("hipEventCreate failed"); }
     build_agg_args(e);
     *out = e;
     return 0;
@@ -239,8 +241,9 @@ void cart_engine_destroy(cart_engine *e) {
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
         if (s.done) (void)hipEventDestroy(s.done);
-    for (auto &ev : e->tev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &r : e->ring)
+        for (auto &ev : r.ev)
+            if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -254,28 +257,48 @@ const char *cart_engine_version(void) {
 
 int cart_engine_set_timing(cart_engine *e, int enabled) {
     if (!e) return fail("engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (enabled && e->ring.empty()) {
+        e->ring.resize(kTimingRing);
+        for (auto &r : e->ring)
+            for (auto &ev : r.ev)
+                if (hipEventCreate(&ev) != hipSuccess) return fail("hipEventCreate failed");
+    }
+    for (auto &r : e->ring) r.n = 0;
+    e->ring_calls = 0;
     e->timing = enabled != 0;
     return 0;
 }
 
-int cart_engine_last_timing(cart_engine *e, const char **names, float *ms, int cap) {
-    if (!e) return fail("engine is NULL");
+int cart_engine_collect_timing(cart_engine *e, const char **names, float *mean_ms, int cap, int *n_calls) {
+    if (!e || !names || !mean_ms) return fail("bad arguments");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(e->mu);
-    if (e->ntimes == 0) return 0;
-    if (hipEventSynchronize(e->tev[e->ntimes]) != hipSuccess) return fail("hipEventSynchronize failed");
-    int n = std::min(cap, e->ntimes);
-    for (int i = 0; i < n; ++i) {
-        names[i] = e->tnames[i];
-        if (hipEventElapsedTime(&ms[i], e->tev[i], e->tev[i + 1]) != hipSuccess) return fail("hipEventElapsedTime failed");
+    int nstages = 0, calls = 0;
+    double sum[kMaxTimings] = {};
+    for (auto &r : e->ring) {
+        if (r.n == 0) continue;
+        if (nstages == 0) { nstages = r.n; for (int i = 0; i < r.n; ++i) names[i < cap ? i : 0] = r.names[i]; }
+        if (r.n != nstages) continue;
+        for (int i = 0; i < r.n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]) != hipSuccess) return fail("hipEventElapsedTime failed");
+            sum[i] += ms;
+        }
+        ++calls;
     }
+    const int n = std::min(cap, nstages);
+    for (int i = 0; i < n; ++i) mean_ms[i] = calls ? (float)(sum[i] / calls) : 0.f;
+    if (n_calls) *n_calls = calls;
     return n;
 }
 
 #define STAGE(name)                                                        \
     do {                                                                   \
-        if (timed && nt < kMaxTimings) {                                   \
-            (void)hipEventRecord(e->tev[nt], stream);                      \
-            e->tnames[nt] = name;                                          \
+        if (rec && nt < kMaxTimings) {                                     \
+            (void)hipEventRecord(rec->ev[nt], stream);                     \
+            rec->names[nt] = name;                                         \
             ++nt;                                                          \
         }                                                                  \
     } while (0)
@@ -296,7 +319,11 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
-    const bool timed = e->timing;
+    TimingRec *rec = nullptr;
+    if (e->timing) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->ring.empty()) { rec = &e->ring[e->ring_calls++ % kTimingRing]; rec->n = 0; }
+    }
     int nt = 0;
     const size_t s0 = (size_t)l.s0;
     uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
@@ -334,10 +361,10 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
             std::swap(src, dst);
         }
     }
-    if (timed) {
+    if (rec) {
+        (void)hipEventRecord(rec->ev[nt], stream);
         std::lock_guard<std::mutex> lk(e->mu);
-        (void)hipEventRecord(e->tev[nt], stream);
-        e->ntimes = nt;
+        rec->n = nt;
     }
     hipError_t err = hipGetLastError();
     release(l);

@@ -139,11 +139,13 @@ enum {
 };
 int cart_debug_read(cart_engine *engine, int frame_slot, int what, void *host_dst, size_t bytes);
 
-/* Device-time of the stages of the last compute call on this thread (ms, hipEvents); names are
- * static strings. Returns the number of entries written (<= cap). Only valid when
- * cart_engine_set_timing(engine, 1) was called before. */
+/* Per-stage device time (hipEvents recorded on the caller's stream around each stage of
+ * cart_compute_disparity[_batch]).  set_timing(1) enables recording and clears the record ring
+ * (the last 256 calls are kept); collect_timing() synchronises the device and returns, per stage,
+ * the MEAN milliseconds per call over the recorded calls (names are static strings).  Returns the
+ * number of stages written (<= cap) and the number of calls averaged in *n_calls. */
 int cart_engine_set_timing(cart_engine *engine, int enabled);
-int cart_engine_last_timing(cart_engine *engine, const char **names, float *ms, int cap);
+int cart_engine_collect_timing(cart_engine *engine, const char **names, float *mean_ms, int cap, int *n_calls);
 
 /* Library / build identification ("cart_engine gfx950 <n kernels>"). */
 const char *cart_engine_version(void);

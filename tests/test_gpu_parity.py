@@ -1,0 +1,302 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact on every integer image / label / histogram.  Small and medium sizes are compared
+stage by stage (census, every path slab, WTA maps, disparity, plane stages); BASELINE.json's full
+sizes are covered by one full oracle comparison plus size-independent properties."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cartslam import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_engine(w, h, D, P, md=4, radius=-1, iters=5, inflight=4, **kw):
+    from cartslam import Engine
+    return Engine(w, h, num_disparities=D, paths=P, min_disparity=md, smoothing_radius=radius,
+                  smoothing_iterations=iters, max_inflight=inflight, **kw)
+
+
+CASES = [
+    # w, h, D, P, min_disp
+    (160, 96, 64, 4, 4),
+    (173, 67, 64, 8, 0),      # ragged: nothing is a multiple of a tile
+    (200, 120, 128, 8, 4),
+    (330, 50, 256, 8, 9),
+    (64, 16, 64, 8, 4),       # image narrower than D: every right feature partly out of range
+    (97, 131, 128, 4, 64),    # tall, max min_disparity
+]
+
+
+@pytest.mark.parametrize("w,h,D,P,md", CASES)
+def test_sgm_stage_by_stage(torch_cuda, w, h, D, P, md):
+    torch = torch_cuda
+    l, r, _ = synth.make_pair(w, h, D, md, seed=1000 + w + D)
+    eng = make_engine(w, h, D, P, md)
+    disp = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+    cl, cr = O.census(l), O.census(r)
+    assert (eng.debug_read(0) == l).all() and (eng.debug_read(1) == r).all()
+    assert (eng.debug_read(2) == cl).all(), "census left"
+    assert (eng.debug_read(3) == cr).all(), "census right"
+    S = np.zeros((h, w, D), np.uint16)
+    for i in range(P):
+        dx, dy = O.path_dir(i)
+        L = O.aggregate_path(cl, cr, D, md, 10, 120, dx, dy)
+        got = eng.debug_read(16 + i)
+        assert (got == L).all(), f"path {i} ({dx},{dy}): {int((got != L).sum())} cells differ"
+        S += L
+    wl, wr = O.wta(S, 12)
+    assert (eng.debug_read(32) == wl).all(), "wta left"
+    assert (eng.debug_read(33) == wr).all(), "wta right"
+    exp = O.lr_check_range(O.median3x3(wl), O.median3x3(wr), l, md)
+    assert (disp == exp).all(), "disparity"
+    eng.close()
+
+
+def test_bgr_pitched_batched(torch_cuda):
+    """BGR input (fused gray conversion), non-tight pitches, a batch of frames, smoothing on."""
+    torch = torch_cuda
+    w, h, D, P, n = 190, 70, 64, 8, 3
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=2, inflight=4)
+    ls, rs = synth.make_batch(n, w, h, D, 4, seed=77, channels=3)
+    lbuf = torch.zeros((n, h + 3, w + 11, 3), dtype=torch.uint8, device="cuda")
+    rbuf = torch.zeros((n, h + 1, w + 5, 3), dtype=torch.uint8, device="cuda")
+    lv, rv = lbuf[:, :h, :w], rbuf[:, :h, :w]
+    lv.copy_(dev(torch, ls)); rv.copy_(dev(torch, rs))
+    obuf = torch.full((n, h + 2, w + 6), 12345, dtype=torch.int16, device="cuda")
+    ov = obuf[:, :h, :w]
+    eng.compute_disparity(lv, rv, out=ov)
+    got = obuf.cpu().numpy()
+    for f in range(n):
+        exp = O.disparity_module(ls[f], rs[f], D, P, 4, radius=2, iterations=2)
+        assert (got[f, :h, :w] == exp).all(), f"frame {f}"
+    assert (got[:, h:, :] == 12345).all() and (got[:, :, w:] == 12345).all(), "wrote outside the image"
+    eng.close()
+
+
+def test_engine_reuse_and_params(torch_cuda):
+    """Same engine called repeatedly gives identical output (workspace reuse); other P1/P2/uniqueness."""
+    torch = torch_cuda
+    w, h, D, P = 128, 48, 64, 4
+    l, r, _ = synth.make_pair(w, h, D, 4, seed=5)
+    eng = make_engine(w, h, D, P, 4, inflight=2, p1=7, p2=90, uniqueness_ratio=5)
+    a = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+    l2, r2, _ = synth.make_pair(w, h, D, 4, seed=6)
+    eng.compute_disparity(dev(torch, l2), dev(torch, r2))
+    b = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+    assert (a == b).all()
+    assert (a == O.disparity_module(l, r, D, P, 4, p1=7, p2=90, uniq=5)).all()
+    eng.close()
+
+
+def test_edge_inputs(torch_cuda):
+    """All-black left image (LR mask everywhere), constant images, extreme contrast."""
+    torch = torch_cuda
+    w, h, D, P = 96, 40, 64, 8
+    eng = make_engine(w, h, D, P, 4)
+    rng = np.random.default_rng(0)
+    cases = [
+        (np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)),
+        (np.full((h, w), 200, np.uint8), np.full((h, w), 200, np.uint8)),
+        (rng.integers(0, 2, (h, w)).astype(np.uint8) * 255, rng.integers(0, 2, (h, w)).astype(np.uint8) * 255),
+        (rng.integers(0, 256, (h, w)).astype(np.uint8), rng.integers(0, 256, (h, w)).astype(np.uint8)),
+    ]
+    for i, (l, r) in enumerate(cases):
+        got = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+        assert (got == O.disparity_module(l, r, D, P, 4)).all(), f"case {i}"
+    eng.close()
+
+
+def test_bad_arguments_fail_loudly(torch_cuda):
+    torch = torch_cuda
+    from cartslam import Engine, EngineError
+    with pytest.raises(EngineError):
+        Engine(100, 50, num_disparities=100)
+    with pytest.raises(EngineError):
+        Engine(100, 50, num_disparities=64, paths=5)
+    with pytest.raises(EngineError):
+        Engine(100, 50, num_disparities=64, p2=230)
+    eng = make_engine(100, 50, 64, 4, inflight=2)
+    l = torch.zeros((3, 50, 100), dtype=torch.uint8, device="cuda")
+    with pytest.raises(EngineError):
+        eng.compute_disparity(l, l)  # 3 frames > max_inflight 2
+    eng.close()
+
+
+@pytest.mark.parametrize("r,it", [(1, 1), (2, 1), (3, 2), (2, 5)])
+def test_interpolate(torch_cuda, r, it):
+    torch = torch_cuda
+    rng = np.random.default_rng(r * 7 + it)
+    w, h = 211, 77
+    d = rng.integers(40, 1400, (2, h, w)).astype(np.int16)
+    d[rng.random(d.shape) < 0.3] = -32768
+    eng = make_engine(w, h, 64, 4, inflight=2)
+    t = dev(torch, d)
+    eng.interpolate(t, r, it, 64, w)
+    got = t.cpu().numpy()
+    for f in range(2):
+        assert (got[f] == O.interpolate(d[f], r, it, 64, w)).all()
+    eng.close()
+
+
+def test_plane_stages(torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    w, h, n = 203, 91, 3
+    d = rng.integers(64, 200, (n, h, w)).astype(np.int16)
+    d[rng.random(d.shape) < 0.15] = -32768
+    d[0, 5, 5] = 32767; d[0, 3, 5] = -32767; d[0, 9, 7] = 32767; d[0, 9, 3] = -32767  # s16 wrap
+    eng = make_engine(w, h, 64, 4, inflight=4)
+    t = dev(torch, d)
+    dd, dh = eng.disparity_derivative(t)
+    dd, dh = dd.cpu().numpy(), dh.cpu().numpy()
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    hist_pf = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    pd = eng.plane_derivative_hist(t, hist).cpu().numpy()
+    eng.plane_derivative_hist(t, hist_pf, per_frame_hist=True)
+    eng.plane_derivative_hist(t, hist)  # cumulative: second call doubles it
+    total = np.zeros(256, np.int64)
+    params = [(6, 18, -5, 6, 11, 0), (-3, 2, 2, 40, 0, 20), (0, 0, 0, 0, 0, 0)]
+    planes_pf = eng.plane_classify(dev(torch, pd), params).cpu().numpy()
+    planes_one = eng.plane_classify(dev(torch, pd), params[0]).cpu().numpy()
+    ids, ncomp = eng.plane_ccl(dev(torch, planes_pf))
+    ids, ncomp = ids.cpu().numpy(), ncomp.cpu().numpy()
+    for f in range(n):
+        a, h2 = O.directional_derivative(d[f])
+        assert (dd[f] == a).all() and (dh[f] == h2).all(), f"dir derivative frame {f}"
+        b, hb = O.plane_derivative(d[f])
+        assert (pd[f] == b).all(), f"plane derivative frame {f}"
+        assert (hist_pf[f].cpu().numpy() == hb).all()
+        total += hb
+        assert (planes_pf[f] == O.classify(b, params[f])).all()
+        assert (planes_one[f] == O.classify(b, params[0])).all()
+        eids, en = O.ccl(planes_pf[f])
+        assert (ids[f] == eids).all() and ncomp[f] == en, f"ccl frame {f}"
+    assert (hist.cpu().numpy() == 2 * total).all()
+    eng.close()
+
+
+def test_ccl_hard_shapes(torch_cuda):
+    """Spirals / combs / checkerboards: long union-find chains and many tiny components."""
+    torch = torch_cuda
+    w, h = 131, 67
+    eng = make_engine(w, h, 64, 4, inflight=4)
+    yy, xx = np.mgrid[0:h, 0:w]
+    shapes = [
+        ((xx + yy) % 2).astype(np.uint8),                       # checkerboard: every pixel its own component
+        np.where(yy % 2 == 0, 0, np.where(xx == (yy // 2 % 2) * (w - 1), 0, 1)).astype(np.uint8),  # serpentine
+        np.where(xx % 3 == 0, 2, (yy // 5 % 2)).astype(np.uint8),
+        np.zeros((h, w), np.uint8),
+    ]
+    p = dev(torch, np.stack(shapes))
+    ids, n = eng.plane_ccl(p)
+    ids, n = ids.cpu().numpy(), n.cpu().numpy()
+    for f, s in enumerate(shapes):
+        e, en = O.ccl(s)
+        assert (ids[f] == e).all() and n[f] == en, f"shape {f}"
+    eng.close()
+
+
+def test_host_peak_finder_matches_oracle():
+    from cartslam import find_peaks, find_plane_params
+    rng = np.random.default_rng(9)
+    for k in range(40):
+        hh = (rng.integers(0, 40, 256) if k % 2 else rng.integers(0, 5, 256) * rng.integers(0, 3000, 256)).astype(np.int32)
+        assert find_peaks(hh) == O.find_peaks(hh)
+        prev = tuple(int(v) for v in rng.integers(-20, 20, 6))
+        ok, p = find_plane_params(hh, prev)
+        eok, ep = O.histogram_peak_params(hh, prev)
+        assert ok == eok and p.as_tuple() == ep
+
+
+def test_golden_fixtures(torch_cuda):
+    torch = torch_cuda
+    from cartslam import find_plane_params
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+    assert files
+    for f in files:
+        z = np.load(f)
+        D, P, md, radius, iters = (int(z[k]) for k in ("D", "P", "min_disp", "radius", "iterations"))
+        l, r = z["left"], z["right"]
+        h, w = l.shape[:2]
+        eng = make_engine(w, h, D, P, md, radius=radius, iters=iters)
+        d = eng.compute_disparity(dev(torch, l), dev(torch, r))
+        assert (d.cpu().numpy() == z["disparity"]).all(), f
+        hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+        pd = eng.plane_derivative_hist(d, hist)
+        assert (pd.cpu().numpy() == z["plane_derivative"]).all() and (hist.cpu().numpy() == z["plane_hist"]).all(), f
+        dd, dh = eng.disparity_derivative(d)
+        assert (dd.cpu().numpy() == z["dir_derivative"]).all() and (dh.cpu().numpy() == z["dir_hist"]).all(), f
+        ok, pp = find_plane_params(hist.cpu().numpy())
+        assert ok == bool(z["plane_params_ok"]) and pp.as_tuple() == tuple(int(v) for v in z["plane_params"]), f
+        planes = eng.plane_classify(pd, pp)
+        assert (planes.cpu().numpy() == z["planes"]).all(), f
+        ids, n = eng.plane_ccl(planes)
+        assert (ids.cpu().numpy() == z["ccl_ids"]).all() and int(n.item()) == int(z["ccl_n"]), f
+        eng.close()
+
+
+@pytest.mark.parametrize("w,h,D,P", [(1242, 375, 64, 4), (1242, 375, 128, 8)])
+def test_full_size_against_oracle(torch_cuda, w, h, D, P):
+    """BASELINE.json configs 2 and 3 at full size: whole disparity module + plane labelling, bit-exact."""
+    torch = torch_cuda
+    l, r, gt = synth.make_pair(w, h, D, 4)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2)
+    d = eng.compute_disparity(dev(torch, l), dev(torch, r))
+    exp = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+    got = d.cpu().numpy()
+    assert (got == exp).all(), f"{int((got != exp).sum())} pixels differ"
+    valid = got != -32768
+    assert valid.mean() > 0.8 and np.median(np.abs(got[valid] / 16.0 - gt[valid])) < 0.5  # it is a disparity map
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    pd = eng.plane_derivative_hist(d, hist)
+    eb, eh = O.plane_derivative(exp)
+    assert (pd.cpu().numpy() == eb).all() and (hist.cpu().numpy() == eh).all()
+    assert int(hist.sum()) <= w * h
+    eng.close()
+
+
+def test_full_size_properties_1080p_d256(torch_cuda):
+    """BASELINE config 4 (1920x1080, D=256, 8 paths): too slow for a full oracle run in a test, so
+    size-independent properties: slab bounds, path starts equal the matching cost, batch == single,
+    determinism, and an oracle check of a full-width strip of rows for the horizontal paths."""
+    torch = torch_cuda
+    w, h, D, P, md = 1920, 1080, 256, 8, 4
+    l, r, _ = synth.make_pair(w, h, D, md)
+    eng = make_engine(w, h, D, P, md, inflight=2)
+    tl, tr = dev(torch, l), dev(torch, r)
+    a = eng.compute_disparity(tl, tr).cpu().numpy()
+    cl, cr = eng.debug_read(2), eng.debug_read(3)
+    assert (cl == O.census(l)).all() and (cr == O.census(r)).all()
+    # horizontal paths are row-local: oracle on a strip of rows must equal the same rows of the slabs
+    ys = slice(500, 508)
+    for i in (2, 3):
+        dx, dy = O.path_dir(i)
+        L = O.aggregate_path(cl[ys], cr[ys], D, md, 10, 120, dx, dy)
+        assert (eng.debug_read(16 + i)[ys] == L).all(), f"path {i}"
+    # vertical/diagonal: first row of a down path == matching cost == first row of any path started there
+    down = eng.debug_read(16 + 0)
+    C0 = O.aggregate_path(cl[:1], cr[:1], D, md, 0, 0, 0, 1)  # P1=P2=0 on one row -> plain cost
+    assert (down[0] == C0[0]).all()
+    assert down.max() <= 151
+    del down
+    both = eng.compute_disparity(torch.stack([tl, tl]), torch.stack([tr, tr])).cpu().numpy()
+    assert (both[0] == a).all() and (both[1] == a).all()
+    assert ((a >= (md - 1) * 16) & (a < (md + D) * 16)).all()
+    eng.close()
