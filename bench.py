@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo-pairs/sec of the dense-stereo hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the whole hot path (disparity module: census -> 8-path SGM -> WTA ->
+medians/LR/range -> interpolate; plane module: vertical derivative + histogram -> plane parameters
+-> classify -> connected components) over one batch of `--batch` synthetic 1242x375 stereo pairs
+per GPU, D=128, inputs resident in HBM.  Frames shard by id across ranks (weak scaling); the only
+exchange is the all-gather of per-frame 256-bin histograms for the plane-parameter schedule.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cart-slam_amd"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+
+
+def alg_bytes_per_pair(w, h, D, P):
+    """gray input, materialised u8 slabs."""
+    return w * h * (2 + 8 + 8 * P + 2 * P * D + 23 + 11)
+
+
+def alg_bytes_aggregate(w, h, D, P):
+    """Path-aggregation launch only: census re-read per path (8 B) + slab write (D B) per pixel and path."""
+    return w * h * (8 * P + P * D)
+
+
+def cpu_baseline(w, h, D, P, seconds_budget=20.0):
+    """Times the CPU oracle (the 'port': oracle/cart_oracle.c, OpenMP) on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O  # cpu_baseline leg: allowed importer of oracle/
+    from cartslam import synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    O.build()
+    l, r, _ = synth.make_pair(w, h, D, 4)
+
+    def one():
+        d = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+        dd, hist = O.plane_derivative(d)
+        ok, pp = O.histogram_peak_params(hist)
+        pl = O.classify(dd, pp)
+        O.ccl(pl)
+
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 10:
+            break
+    return {"value": round(n / el, 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} pair(s) {w}x{h} D={D} {P} paths + plane labelling + CCL, OpenMP oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--disparities", type=int, default=128)
+    ap.add_argument("--paths", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cartslam import Engine, synth
+    from cartslam.pipeline import StereoPipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
+                 max_inflight=B, device_id=local_rank)
+    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True)
+    # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
+    n_distinct = min(B, 4)
+    ls, rs = synth.make_batch(n_distinct, w, h, D, 4, first_frame=rank * n_distinct)
+    reps = (B + n_distinct - 1) // n_distinct
+    left = torch.from_numpy(np.concatenate([ls] * reps)[:B]).cuda()
+    right = torch.from_numpy(np.concatenate([rs] * reps)[:B]).cuda()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.process_batch(left, right)
+    torch.cuda.synchronize()
+    eng.set_timing(True)  # hipEvents around each stage, on the stream the kernels are launched on
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.process_batch(left, right)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    stages, ncalls = eng.collect_timing()
+    eng.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        agg_ms = stages.get("aggregate", 0.0)  # mean duration of ONE aggregate launch (B frames)
+        agg_bytes = alg_bytes_aggregate(w, h, D, P) * B
+        achieved = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                key = f"aggregate_{w}x{h}_D{D}_P{P}_B{B}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        device_ms_per_pair = sum(stages.values()) / B if stages else None
+        out = {
+            "metric": "stereo-pairs/sec @1242x375xD=128; achieved HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "stereo-pairs/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{w}x{h} gray stereo, D={D}, {P}-direction SGM + interpolate(r=2,it=1) + plane "
+                                   f"labelling (histogram_peak) + CCL; BASELINE.json configs[2]",
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "aggregate_kernel (all paths of all frames in one launch)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "alg_bytes_per_launch": agg_bytes, "launch_ms": round(agg_ms, 4), "launches_timed": ncalls},
+            "stages_ms_per_batch": {k: round(v, 4) for k, v in stages.items()},
+            "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
+            "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, h, D, P)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

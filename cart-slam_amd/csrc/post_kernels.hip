@@ -168,10 +168,14 @@ void launch_classify(const int16_t *deriv, size_t step, size_t fs, const Classif
     hipLaunchKernelGGL(classify_kernel, grid, block, 0, s, deriv, step, fs, params, per_frame, planes, pstep, pfs, w, h);
 }
 
-// ------------------------------------------------------------------ connected components (union-find, min-index roots)
+// ------------------------------------------------------------------ connected components (run-based union-find)
+// 1. ccl_runs:    every pixel links to the first pixel of its horizontal run (block scan per row),
+// 2. ccl_merge:   one union per pair of vertically touching runs (only where a run starts above or
+//                 below), atomicMin-based so roots are the minimal linear index (oracle S12),
+// 3. ccl_compress: run heads resolve their root, 4. ccl_final: every pixel reads root-of-run-head.
 // Parent links only ever decrease (atomicMin) and always point inside the component, so a stale
 // read (per-XCD L2s are not coherent inside a launch) can only lengthen a walk, never break it;
-// the flatten pass runs in a later launch and therefore sees every link.
+// later passes run in later launches and therefore see every link.
 __device__ __forceinline__ int ccl_find(int32_t *L, int i) {
     int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != i) { i = p; p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -189,38 +193,79 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void ccl_init_kernel(int32_t *work, int w, int h, size_t npx) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
-    if (x >= w || y >= h) return;
-    work[(size_t)frame * npx + (size_t)y * w + x] = y * w + x;
+__global__ __launch_bounds__(256) void ccl_runs_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
+                                                       int w, int h, size_t npx) {
+    __shared__ int wave_tot[4];
+    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
+    int32_t *L = work + (size_t)frame * npx + (size_t)y * w;
+    int carry = -1;  // head of the run that continues from the previous 256-pixel chunk
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + tid;
+        const int c = x < w ? row[x] : 255;
+        const int cp = (x > 0 && x < w) ? row[x - 1] : 254;
+        int s = (x < w && c != cp) ? x : -1;  // run head -> its own column
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {  // inclusive max-scan inside the wave
+            const int n = __shfl_up(s, o);
+            if (lane >= o) s = max(s, n);
+        }
+        if (lane == 63) wave_tot[wid] = s;
+        __syncthreads();
+        int prefix = carry, all = carry;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < wid) prefix = max(prefix, wave_tot[k]);
+            all = max(all, wave_tot[k]);
+        }
+        s = max(s, prefix);
+        if (x < w) L[x] = c <= 1 ? y * w + s : -1;
+        carry = all;
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
                                                         int w, int h, size_t npx) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y + 1, frame = blockIdx.z;
     if (x >= w || y >= h) return;
-    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
+    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y), *up = row_ptr(planes, pfs, pstep, frame, y - 1);
     const uint8_t c = row[x];
-    if (c > 1) return;
+    if (c > 1 || up[x] != c) return;
+    const bool head = x == 0 || row[x - 1] != c, up_head = x == 0 || up[x - 1] != c;
+    if (!head && !up_head) return;  // this pair of runs is united at an earlier column
     int32_t *L = work + (size_t)frame * npx;
-    const int i = y * w + x;
-    if (x > 0 && row[x - 1] == c) ccl_union(L, i, i - 1);
-    if (y > 0 && row_ptr(planes, pfs, pstep, frame, y - 1)[x] == c) ccl_union(L, i, i - w);
+    ccl_union(L, L[y * w + x], L[(y - 1) * w + x]);
 }
 
-__global__ __launch_bounds__(256) void ccl_flatten_kernel(const uint8_t *planes, size_t pstep, size_t pfs,
-                                                          const int32_t *work, int32_t *ids, size_t istep, size_t ifs,
-                                                          int32_t *ncomp, int w, int h, size_t npx) {
+__global__ __launch_bounds__(256) void ccl_compress_kernel(int32_t *work, int32_t *ncomp, int w, int h, size_t npx) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= w || y >= h) return;
-    const uint8_t c = row_ptr(planes, pfs, pstep, frame, y)[x];
+    int32_t *L = work + (size_t)frame * npx;
+    const int i = y * w + x;
+    const int p = L[i];
+    if (p < 0) return;
+    if (p == i) {  // a root: nothing links it further, nobody rewrites it in this pass
+        if (ncomp) atomicAdd(&ncomp[frame], 1);
+        return;
+    }
+    int r = p;
+    int q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (q == r) return;  // already links straight to a root
+    while (q != r) { r = q; q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // writing the root into a link keeps the forest valid whatever other threads read meanwhile
+    __hip_atomic_store(&L[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int w,
+                                                        int h, size_t npx) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
     const int32_t *L = work + (size_t)frame * npx;
-    int i = y * w + x, r = -1;
-    if (c <= 1) {
-        r = i;
-        int p = L[r];
-        while (p != r) { r = p; p = L[r]; }
-        if (r == i && ncomp) atomicAdd(&ncomp[frame], 1);
+    int r = L[y * w + x];
+    if (r >= 0) {
+        int q = L[r];
+        while (q != r) { r = q; q = L[r]; }  // at most a couple of hops after ccl_compress
     }
     row_ptr(ids, ifs, istep, frame, y)[x] = r;
 }
@@ -230,12 +275,15 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     const size_t npx = (size_t)w * h;
     dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
     if (ncomp) (void)hipMemsetAsync(ncomp, 0, sizeof(int32_t) * (size_t)n_frames, s);
-    hipLaunchKernelGGL(ccl_init_kernel, grid, block, 0, s, work, w, h, npx);
-    hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, s, planes, pstep, pfs, work, w, h, npx);
-    hipLaunchKernelGGL(ccl_flatten_kernel, grid, block, 0, s, planes, pstep, pfs, (const int32_t *)work, ids, istep, ifs,
-                       ncomp, w, h, npx);
+    hipLaunchKernelGGL(ccl_runs_kernel, dim3(h, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx);
+    if (h > 1) {
+        dim3 mgrid((w + 63) / 64, (h - 1 + 3) / 4, n_frames);
+        hipLaunchKernelGGL(ccl_merge_kernel, mgrid, block, 0, s, planes, pstep, pfs, work, w, h, npx);
+    }
+    hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, work, ncomp, w, h, npx);
+    hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 12; }
+int kernel_count() { return 13; }
 
 }  // namespace cart_amd
