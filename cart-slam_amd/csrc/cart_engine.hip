@@ -55,7 +55,9 @@ struct cart_engine {
     float uniq;
     // workspaces, each [max_inflight][...]
     uint8_t *gray_l = nullptr, *gray_r = nullptr;
-    uint32_t *cen_l = nullptr, *cen_r = nullptr;
+    uint32_t *cen_l = nullptr, *cen_r = nullptr;      // point `cen_slack` elements into their allocations
+    uint32_t *cen_l_alloc = nullptr, *cen_r_alloc = nullptr;
+    size_t cen_slack = 0;
     uint8_t *slabs = nullptr;
     uint16_t *wta_l = nullptr;
     uint32_t *right_pk = nullptr;
@@ -132,6 +134,7 @@ void build_agg_args(cart_engine *e) {
     static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
     a.ndirs = g.P;
     int blk = 0;
+    const int lpb = agg_lines_per_block(g.D);
     for (int i = 0; i < g.P; ++i) {
         DirDesc &d = a.dirs[i];
         d.dx = order8[i].dx; d.dy = order8[i].dy; d.path = order8[i].path;
@@ -139,7 +142,7 @@ void build_agg_args(cart_engine *e) {
         else if (d.dx == 0) { d.nlines = g.w; d.jmin = 0; }
         else { d.nlines = g.w + g.h - 1; d.jmin = d.dx > 0 ? -(g.h - 1) : 0; }
         d.blk0 = blk;
-        blk += (d.nlines + kLinesPerBlock - 1) / kLinesPerBlock;
+        blk += (d.nlines + lpb - 1) / lpb;
     }
     a.blocks_per_frame = blk;
     a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
@@ -207,8 +210,11 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     int rc = 0;
     rc |= dev_alloc(&e->gray_l, n * g.npx);
     rc |= dev_alloc(&e->gray_r, n * g.npx);
-    rc |= dev_alloc(&e->cen_l, n * g.census_elems);
-    rc |= dev_alloc(&e->cen_r, n * g.census_elems);
+    // the cooperative window loads of waves whose leading scan lines are still outside the image touch
+    // addresses up to (h + D + min_disp + 64) features before / after a frame's census plane
+    e->cen_slack = (size_t)g.h + 1024;
+    rc |= dev_alloc(&e->cen_l_alloc, n * g.census_elems + 2 * e->cen_slack);
+    rc |= dev_alloc(&e->cen_r_alloc, n * g.census_elems + 2 * e->cen_slack);
     rc |= dev_alloc(&e->slabs, n * g.P * g.slab_bytes);
     rc |= dev_alloc(&e->wta_l, n * g.npx);
     rc |= dev_alloc(&e->right_pk, n * g.npx);
@@ -216,9 +222,11 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     rc |= dev_alloc(&e->tmp_b, n * g.npx);
     rc |= dev_alloc(&e->ccl_work, n * g.npx);
     if (rc) { cart_engine_destroy(e); return -1; }
+    e->cen_l = e->cen_l_alloc + e->cen_slack;
+    e->cen_r = e->cen_r_alloc + e->cen_slack;
     // the census padding columns are never written again: out-of-image right features read as 0 (oracle S3)
-    if (hipMemset(e->cen_l, 0, n * g.census_elems * 4) != hipSuccess ||
-        hipMemset(e->cen_r, 0, n * g.census_elems * 4) != hipSuccess) {
+    if (hipMemset(e->cen_l_alloc, 0, (n * g.census_elems + 2 * e->cen_slack) * 4) != hipSuccess ||
+        hipMemset(e->cen_r_alloc, 0, (n * g.census_elems + 2 * e->cen_slack) * 4) != hipSuccess) {
         cart_engine_destroy(e);
         return fail("hipMemset of census workspace failed");
     }
@@ -236,7 +244,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l, e->cen_r, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)

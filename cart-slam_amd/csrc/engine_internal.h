@@ -10,7 +10,6 @@
 namespace cart_amd {
 
 constexpr int kMaxPaths = 8;
-constexpr int kLinesPerBlock = 16;   // one 16-lane DPP row per scan line, 256-thread blocks
 constexpr int kWtaTileX = 64;        // pixels of one row handled by one WTA block
 constexpr int kMaxBatchArgs = 128;   // frames per classify launch (params travel as kernel args)
 constexpr uint32_t kWtaInvalid = 0xFFFFu;
@@ -41,6 +40,7 @@ struct AggArgs {
     Geometry g;
     int ndirs;
     int blocks_per_frame;
+    int n_frames;        // filled by launch_aggregate
     DirDesc dirs[kMaxPaths];
 };
 
@@ -53,6 +53,7 @@ struct ImageBatch {   // pitched caller image(s)
 void launch_census(const ImageBatch &left, const ImageBatch &right, int channels, int n_frames,
                    uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l, uint32_t *cen_r, uint32_t *right_pk,
                    const Geometry &g, hipStream_t s);
+int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is owned by D/16 lanes)
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s);

@@ -146,92 +146,293 @@ void launch_census(const ImageBatch &left, const ImageBatch &right, int channels
 }
 
 // ------------------------------------------------------------------ path aggregation
-// All directions of all frames in ONE launch (blockIdx.x -> direction + 16 scan lines,
+// All directions of all frames in ONE launch (blockIdx.x -> direction + a group of scan lines,
 // blockIdx.y -> frame).  Every direction is a set of independent 1-D lines: vertical and
-// diagonal lines are indexed by their (skewed) entry column so no state ever crosses lanes
-// other than the +-1 disparity neighbours inside a 16-lane row.
-template <int DPL>
-__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
-    const Geometry &g = a.g;
-    const int frame = blockIdx.y;
-    const int b = blockIdx.x;
-    int di = 0;
-    for (int i = 1; i < a.ndirs; ++i)
-        if (b >= a.dirs[i].blk0) di = i;
-    const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
-    const int lane16 = threadIdx.x & 15;
-    const int line = (b - a.dirs[di].blk0) * kLinesPerBlock + (threadIdx.x >> 4);
-    if (line >= a.dirs[di].nlines) return;  // whole 16-lane rows leave together
-    const int j = a.dirs[di].jmin + line;
+// diagonal lines are indexed by their (skewed) entry column so no state ever crosses pixels.
+//
+// The kernel is VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU ~ 93 % of SIMD time in the first,
+// 32-bit version), so the recurrence runs on PACKED u16 pairs (v_pk_min_u16 / v_pk_add_u16: two
+// disparities per instruction).  A pixel is owned by LPP = D/16 adjacent lanes, 16 disparities per
+// lane held in 8 registers with a split-halves layout  reg i = (L[d0+i], L[d0+i+8]) :
+//   * the d-1 / d+1 neighbour vectors of reg i are simply reg i-1 / reg i+1 (register renaming);
+//     only reg 0 / reg 7 need one v_perm_b32 that stitches in the neighbouring lane's value
+//     (DPP row_shr/row_shl), and that same v_perm writes 0xFFFF (= never chosen) at the ends of the
+//     disparity range through a per-lane selector,
+//   * the matching cost is popcount(xor) with the "- min" of the recurrence folded into
+//     v_bcnt_u32_b32's accumulate operand, packed by one v_perm_b32 per pair,
+//   * the u8 slab bytes are produced by v_perm_b32 byte gathers (8 per 16 cells),
+//   * min over D = packed min tree + DPP (quad_perm / row_half_mirror / row_mirror) on the
+//     replicated pair, which doubles as the packed (m,m) operand of the next step.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-    int xs, ys, t0, t1;
-    if (dy != 0) {
-        ys = dy > 0 ? 0 : g.h - 1;
-        xs = j;
-        if (dx > 0) { t0 = max(0, -j); t1 = min(g.h, g.w - j); }
-        else if (dx < 0) { t0 = max(0, j - g.w + 1); t1 = min(g.h, j + 1); }
-        else { t0 = 0; t1 = g.h; }
-    } else {
-        ys = j; xs = dx > 0 ? 0 : g.w - 1; t0 = 0; t1 = g.w;
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t perm(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi_src, lo_src, sel);  // selector bytes: 0-3 = lo_src, 4-7 = hi_src, 0x0c = 0x00, 0x0d = 0xFF
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+// all-reduce (min) over the LPP lanes that own one pixel; v is an unsigned key
+template <int LPP>
+__device__ __forceinline__ uint32_t group_allmin(uint32_t v) {
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    if constexpr (LPP >= 8) v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    if constexpr (LPP >= 16) v = min(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+template <int LPP>
+__device__ __forceinline__ uint32_t group_allsum(uint32_t v) {
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    if constexpr (LPP >= 8) v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    if constexpr (LPP >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+struct CensusRegs {
+    uint32_t fl;
+    uint32_t r[16];
+};
+
+__device__ __forceinline__ void load_census(const uint32_t *pl, const uint32_t *pr, CensusRegs &c) {
+    c.fl = *pl;
+    load_u32s<16>(pr, c.r);
+}
+
+template <int LPP>
+__device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const CensusRegs &c, uint32_t sel_lo,
+                                         uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, uint8_t *po) {
+    // matching cost minus the running minimum, packed like the state: cm[i] = (C[d0+i]-m, C[d0+i+8]-m)
+    uint32_t negm = 0u - (mm & 0xffffu);
+    asm volatile("" : "+v"(negm));  // keep "+ (-m)" an add so it folds into v_bcnt_u32_b32's accumulate operand
+    uint32_t cm[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t clo = (uint32_t)__builtin_popcount(c.fl ^ c.r[15 - i]) + negm;
+        const uint32_t chi = (uint32_t)__builtin_popcount(c.fl ^ c.r[7 - i]) + negm;
+        cm[i] = perm(chi, clo, 0x05040100u);
     }
-    if (t0 >= t1) return;
-    const int x = xs + dx * t0, y = ys + dy * t0;
-    const int d0 = lane16 * DPL;
-
-    const uint32_t *pl = a.cen_l + (size_t)frame * g.census_elems + (size_t)y * g.cpitch + g.cpadl + x;
-    const uint32_t *pr = a.cen_r + (size_t)frame * g.census_elems + (size_t)y * g.cpitch + g.cpadl + x -
-                         g.min_disp - d0 - (DPL - 1);
-    const ptrdiff_t cstride = (ptrdiff_t)dy * g.cpitch + dx;
-    uint8_t *po = a.slabs + ((size_t)(frame * g.P + a.dirs[di].path) * g.npx + (size_t)y * g.w + x) * g.D + d0;
-    const ptrdiff_t ostride = ((ptrdiff_t)dy * g.w + dx) * g.D;
-
-    const uint32_t p1 = (uint32_t)g.p1, p2 = (uint32_t)g.p2;
-    constexpr uint32_t INF = 0x7fffu;
-    uint32_t dp[DPL];
+    const uint32_t mp2 = pk_add(mm, p2p2);
+    // neighbour vectors at the two ends: (prev lane's L[d0-1], own L[d0+7]) and (own L[d0+8], next lane's L[d0+16])
+    const uint32_t lo0 = perm(a[7], dpp_mov<DPP_ROW_SHR1>(a[7]), sel_lo);
+    const uint32_t hi7 = perm(dpp_mov<DPP_ROW_SHL1>(a[0]), a[0], sel_hi);
+    uint32_t n[8];
 #pragma unroll
-    for (int k = 0; k < DPL; ++k) dp[k] = 0;
-    uint32_t last_min = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t lo = i == 0 ? lo0 : a[i - 1];
+        const uint32_t hi = i == 7 ? hi7 : a[i + 1];
+        uint32_t t = pk_add(pk_min(lo, hi), p1p1);
+        t = pk_min(pk_min(t, a[i]), mp2);
+        n[i] = pk_add(t, cm[i]);  // oracle S4, both halves at once
+    }
+    // u8 slab bytes in disparity order d0 .. d0+15
+    const uint32_t q01 = perm(n[1], n[0], 0x06020400u), q23 = perm(n[3], n[2], 0x06020400u);
+    const uint32_t q45 = perm(n[5], n[4], 0x06020400u), q67 = perm(n[7], n[6], 0x06020400u);
+    uint4 o;
+    o.x = perm(q23, q01, 0x05040100u); o.y = perm(q67, q45, 0x05040100u);
+    o.z = perm(q23, q01, 0x07060302u); o.w = perm(q67, q45, 0x07060302u);
+    *reinterpret_cast<uint4 *>(po) = o;
+    // min over the pixel's D disparities, replicated into both halves
+    uint32_t x = pk_min(pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3])), pk_min(pk_min(n[4], n[5]), pk_min(n[6], n[7])));
+    x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
+    mm = group_allmin<LPP>(x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = n[i];
+}
 
-    uint32_t fl_n = *pl;
-    uint32_t r_n[DPL];
-    load_u32s<DPL>(pr, r_n);
+// ---- LDS staging of the right-census window (vertical + diagonal directions) ----
+// The P = 64/LPP pixels a wave works on at one step are adjacent columns of one image row, so the
+// P windows of D right features overlap in all but P-1 entries.  Per-lane window loads cost 4 B per
+// DP cell through the L1->VGPR path (rocprofv3: TA_BUSY 76 %, TD_BUSY 78 %, 3x line-access inflation
+// from the 4-byte-aligned dwordx4 loads) and bound the first two versions of this kernel; instead the
+// wave loads the union window once, coalesced (NLD dwords per lane), writes it to a wave-private LDS
+// buffer and every lane reads its 16 features from there.  Window dword w lives at LDS slot
+// w + 4*(w>>4): the 4-dword pad per 16 makes the lanes' 16-dword stride conflict-free on the 32 banks.
+template <int LPP>
+struct Win {
+    static constexpr int P = 64 / LPP;              // pixels (scan lines) per wave
+    static constexpr int D = 16 * LPP;
+    static constexpr int MAXW = D - 2 + P;          // last window dword that is ever read
+    static constexpr int SLOTS = MAXW + 4 * (MAXW >> 4) + 1;
+    static constexpr int NLD = (SLOTS + 63) / 64;   // cooperative dword loads per lane and step
+    static constexpr int BUF = NLD * 64;            // dwords per LDS buffer
+    static constexpr int KX = 16 - (P - 1);         // first k whose slot may sit behind one more pad
+};
 
-    for (int t = t0; t < t1; ++t) {
-        const uint32_t fl = fl_n;
-        uint32_t cost[DPL];
+template <int LPP>
+__device__ __forceinline__ void win_read(const uint32_t *lds_buf, int base_slot, const int (&xslot)[Win<LPP>::P - 1],
+                                         uint32_t (&r)[16]) {
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) cost[k] = (uint32_t)__builtin_popcount(fl ^ r_n[DPL - 1 - k]);
-        pl += cstride; pr += cstride;
-        if (t + 1 < t1) {  // prefetch the next pixel's features while this one is reduced
-            fl_n = *pl;
-            load_u32s<DPL>(pr, r_n);
-        }
-        // oracle S4: L(d) = C(d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, m+P2) - m
-        const uint32_t prev_hi = dpp_keep<DPP_ROW_SHR1>(INF, dp[DPL - 1]);  // lane-1's top disparity
-        const uint32_t next_lo = dpp_keep<DPP_ROW_SHL1>(INF, dp[0]);        // lane+1's bottom disparity
-        const uint32_t mp2 = last_min + p2;
-        uint32_t nd[DPL];
-        uint32_t lmin = 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            const uint32_t lo = k == 0 ? prev_hi : dp[k - 1];
-            const uint32_t hi = k == DPL - 1 ? next_lo : dp[k + 1];
-            uint32_t tt = min(lo, hi) + p1;
-            tt = min(tt, dp[k]);
-            tt = min(tt, mp2);
-            nd[k] = tt - last_min + cost[k];
-            lmin = min(lmin, nd[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) dp[k] = nd[k];
-        last_min = row_allmin(lmin);
-        store_u8s<DPL>(po, nd);
-        po += ostride;
+    for (int k = 0; k < 16; ++k) {
+        if (k < Win<LPP>::KX) r[k] = lds_buf[base_slot + k];
+        else r[k] = lds_buf[xslot[k - Win<LPP>::KX]];
     }
 }
 
-void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s) {
-    dim3 grid(a.blocks_per_frame, n_frames), block(256);
+template <int LPP>
+__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
+    using WN = Win<LPP>;
+    constexpr int P = WN::P;
+    constexpr int LINES_PER_BLOCK = 4 * P;
+    __shared__ uint32_t s_win[4][2][WN::BUF];
+    const Geometry &g = a.g;
+    // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
+    // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
+    int di = 0;
+    for (int i = 1; i < a.ndirs; ++i)
+        if ((int)blockIdx.x >= a.dirs[i].blk0 * a.n_frames) di = i;
+    const int nblk = (a.dirs[di].nlines + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK;
+    const int rb = blockIdx.x - a.dirs[di].blk0 * a.n_frames;
+    const int frame = rb / nblk;
+    const int b = rb - frame * nblk + a.dirs[di].blk0;
+    const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int gl = lane % LPP, pg = lane / LPP;  // lane inside the pixel's lane group, pixel group inside the wave
+    const int line0 = (b - a.dirs[di].blk0) * LINES_PER_BLOCK + wid * P;  // wave-uniform
+    const int line = line0 + pg;
+    const int nlines = a.dirs[di].nlines;
+    if (line0 >= nlines) return;  // whole wave idle
+    const int d0 = gl * 16;
+    const uint32_t p1p1 = (uint32_t)g.p1 * 0x10001u, p2p2 = (uint32_t)g.p2 * 0x10001u;
+    // selectors of the two stitching v_perm: 0x0d bytes inject 0xFFFF where d-1 / d+1 leave [0, D)
+    const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
+    const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
+    const uint32_t *cen_l = a.cen_l + (size_t)frame * g.census_elems;
+    const uint32_t *cen_r = a.cen_r + (size_t)frame * g.census_elems;
+    uint8_t *slab = a.slabs + (size_t)(frame * g.P + a.dirs[di].path) * g.slab_bytes;
+
+    uint32_t st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = 0;
+    uint32_t mm = 0;
+    CensusRegs ca, cb;
+
+    if (dy == 0) {
+        // ---- horizontal scans: the wave's pixels sit on P different rows, nothing to share; per-lane loads.
+        // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
+        __builtin_amdgcn_s_setprio(3);
+        if (line >= nlines) return;
+        const int y = a.dirs[di].jmin + line;
+        const int x = dx > 0 ? 0 : g.w - 1, t1 = g.w;
+        const uint32_t *pl = cen_l + (size_t)y * g.cpitch + g.cpadl + x;
+        const uint32_t *pr = cen_r + (size_t)y * g.cpitch + g.cpadl + x - g.min_disp - d0 - 15;
+        uint8_t *po = slab + ((size_t)y * g.w + x) * g.D + d0;
+        const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
+        load_census(pl, pr, ca);
+        int t = 0;
+        for (; t + 1 < t1; t += 2) {
+            pl += cstride; pr += cstride;
+            load_census(pl, pr, cb);  // prefetch the next pixel's features while this one is reduced
+            agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
+            po += ostride;
+            if (t + 2 < t1) { pl += cstride; pr += cstride; load_census(pl, pr, ca); }
+            agg_step<LPP>(st, mm, cb, sel_lo, sel_hi, p1p1, p2p2, po);
+            po += ostride;
+        }
+        if (t < t1) agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
+        return;
+    }
+
+    // ---- vertical / diagonal scans: lines are indexed by their (skewed) entry column j
+    const int j = a.dirs[di].jmin + line;
+    const int ys = dy > 0 ? 0 : g.h - 1;
+    int t0, t1;  // this lane group's active steps
+    if (dx > 0) { t0 = max(0, -j); t1 = min(g.h, g.w - j); }
+    else if (dx < 0) { t0 = max(0, j - g.w + 1); t1 = min(g.h, j + 1); }
+    else { t0 = 0; t1 = g.h; }
+    if (line >= nlines) { t0 = 0; t1 = 0; }
+    // wave-uniform step range = union over the wave's (adjacent) lines
+    const int jf = a.dirs[di].jmin + line0, jl = a.dirs[di].jmin + min(line0 + P, nlines) - 1;
+    int tb, te;
+    if (dx > 0) { tb = max(0, -jl); te = min(g.h, g.w - jf); }
+    else if (dx < 0) { tb = max(0, jf - g.w + 1); te = min(g.h, jl + 1); }
+    else { tb = 0; te = g.h; }
+    if (tb >= te) return;
+
+    // cooperative window load: LDS slot l = 64*i + lane  <-  window dword 16*(l/20) + min(l%20, 15)
+    int goff[WN::NLD];
+#pragma unroll
+    for (int i = 0; i < WN::NLD; ++i) {
+        const int l = 64 * i + lane;
+        goff[i] = 16 * (l / 20) + min(l % 20, 15);
+    }
+    // this lane's 16 features: window dwords wl .. wl+15, wl = pg + D-16 - 16*gl
+    const int wl = pg + WN::D - 16 - d0;
+    const int base_slot = wl + 4 * (wl >> 4);
+    int xslot[P - 1];
+#pragma unroll
+    for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
+    uint32_t *buf0 = &s_win[wid][0][0], *buf1 = &s_win[wid][1][0];
+
+    // pointers at step tb; x of the wave's first line / of this lane's line
+    const int yb = ys + dy * tb;
+    const int xf = jf + dx * tb, xo = j + dx * tb;
+    const uint32_t *pw = cen_r + (size_t)yb * g.cpitch + g.cpadl + xf - g.min_disp - (WN::D - 1);  // window start
+    const uint32_t *pl = cen_l + (size_t)yb * g.cpitch + g.cpadl + xo;
+    const ptrdiff_t cstride = (ptrdiff_t)dy * g.cpitch + dx;
+    uint8_t *po = slab + ((ptrdiff_t)yb * g.w + xo) * g.D + d0;
+    const ptrdiff_t ostride = ((ptrdiff_t)dy * g.w + dx) * g.D;
+
+    uint32_t gw[WN::NLD];
+#pragma unroll
+    for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
+    ca.fl = *pl;
+    int t = tb;
+    for (; t + 1 < te; t += 2) {
+        pw += cstride; pl += cstride;
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) gw[i] = pw[goff[i]];  // window of step t+1, in flight during step t
+        cb.fl = *pl;
+        if (t >= t0 && t < t1) {
+            win_read<LPP>(buf0, base_slot, xslot, ca.r);
+            agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
+        }
+        po += ostride;
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = gw[i];
+        if (t + 2 < te) {
+            pw += cstride; pl += cstride;
+#pragma unroll
+            for (int i = 0; i < WN::NLD; ++i) gw[i] = pw[goff[i]];
+            ca.fl = *pl;
+        }
+        if (t + 1 >= t0 && t + 1 < t1) {
+            win_read<LPP>(buf1, base_slot, xslot, cb.r);
+            agg_step<LPP>(st, mm, cb, sel_lo, sel_hi, p1p1, p2p2, po);
+        }
+        po += ostride;
+        if (t + 2 < te) {
+#pragma unroll
+            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = gw[i];
+        }
+    }
+    if (t < te && t >= t0 && t < t1) {
+        win_read<LPP>(buf0, base_slot, xslot, ca.r);
+        agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
+    }
+}
+
+int agg_lines_per_block(int D) { return 256 / (D / 16); }
+
+void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
+    AggArgs a = a_in;
+    a.n_frames = n_frames;
+    dim3 grid(a.blocks_per_frame * n_frames), block(256);
     switch (a.g.D) {
         case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, 0, s, a); break;
         case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, 0, s, a); break;
