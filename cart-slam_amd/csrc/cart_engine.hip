@@ -67,6 +67,9 @@ struct cart_engine {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
+    int chunks = 1;                 // sub-batches per call (software pipeline over aux[0..1])
+    hipStream_t aux[2] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {};
     bool timing = false;
     std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
     size_t ring_calls = 0;
@@ -132,11 +135,15 @@ void build_agg_args(cart_engine *e) {
     // start first; slab index `path` keeps the oracle's order {down, up, right, left, diagonals}.
     struct D { int dx, dy, path; };
     static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
-    a.ndirs = g.P;
-    int blk = 0;
+    // diagnostic only (timing experiments; results are wrong when directions are dropped):
+    // CART_DEBUG_DIRMASK = bit mask over the launch-order directions to keep
+    unsigned mask = 0xffu;
+    if (const char *m = std::getenv("CART_DEBUG_DIRMASK")) mask = (unsigned)std::strtoul(m, nullptr, 0);
+    int blk = 0, nd = 0;
     const int lpb = agg_lines_per_block(g.D);
     for (int i = 0; i < g.P; ++i) {
-        DirDesc &d = a.dirs[i];
+        if (!((mask >> i) & 1u)) continue;
+        DirDesc &d = a.dirs[nd++];
         d.dx = order8[i].dx; d.dy = order8[i].dy; d.path = order8[i].path;
         if (d.dy == 0) { d.nlines = g.h; d.jmin = 0; }
         else if (d.dx == 0) { d.nlines = g.w; d.jmin = 0; }
@@ -144,6 +151,7 @@ void build_agg_args(cart_engine *e) {
         d.blk0 = blk;
         blk += (d.nlines + lpb - 1) / lpb;
     }
+    a.ndirs = nd;
     a.blocks_per_frame = blk;
     a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
 }
@@ -212,7 +220,8 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     rc |= dev_alloc(&e->gray_r, n * g.npx);
     // the cooperative window loads of waves whose leading scan lines are still outside the image touch
     // addresses up to (h + D + min_disp + 64) features before / after a frame's census plane
-    e->cen_slack = (size_t)g.h + 1024;
+    // and the software-pipelined prefetches run up to 3 rows past the first / last step
+    e->cen_slack = (size_t)4 * g.cpitch + g.h + 1024;
     rc |= dev_alloc(&e->cen_l_alloc, n * g.census_elems + 2 * e->cen_slack);
     rc |= dev_alloc(&e->cen_r_alloc, n * g.census_elems + 2 * e->cen_slack);
     rc |= dev_alloc(&e->slabs, n * g.P * g.slab_bytes);
@@ -237,6 +246,14 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
             return fail("hipEventCreate failed");
         }
     build_agg_args(e);
+    if (const char *c = std::getenv("CART_CHUNKS")) e->chunks = std::max(1, std::atoi(c));
+    for (int s = 0; s < 2; ++s)
+        if (hipStreamCreateWithFlags(&e->aux[s], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join[s], hipEventDisableTiming) != hipSuccess) {
+            cart_engine_destroy(e);
+            return fail("stream/event creation failed");
+        }
+    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { cart_engine_destroy(e); return fail("hipEventCreate failed"); }
     *out = e;
     return 0;
 }
@@ -252,6 +269,11 @@ void cart_engine_destroy(cart_engine *e) {
     for (auto &r : e->ring)
         for (auto &ev : r.ev)
             if (ev) (void)hipEventDestroy(ev);
+    for (int s = 0; s < 2; ++s) {
+        if (e->aux[s]) (void)hipStreamDestroy(e->aux[s]);
+        if (e->ev_join[s]) (void)hipEventDestroy(e->ev_join[s]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 
@@ -333,46 +355,73 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
         if (!e->ring.empty()) { rec = &e->ring[e->ring_calls++ % kTimingRing]; rec->n = 0; }
     }
     int nt = 0;
-    const size_t s0 = (size_t)l.s0;
-    uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
-    uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
-    uint8_t *slabs = e->slabs + s0 * g.P * g.slab_bytes;
-    uint16_t *wl = e->wta_l + s0 * g.npx;
-    uint32_t *rpk = e->right_pk + s0 * g.npx;
-    int16_t *ta = e->tmp_a + s0 * g.npx, *tb = e->tmp_b + s0 * g.npx;
-
-    STAGE("census");
-    ImageBatch lb{left, left_step, left_frame_stride}, rb{right, right_step, right_frame_stride};
-    launch_census(lb, rb, channels, n_frames, gl, gr, cl, cr, rpk, g, stream);
-    STAGE("aggregate");
-    AggArgs a = e->agg;
-    a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
-    launch_aggregate(a, n_frames, stream);
-    STAGE("wta");
-    launch_wta(slabs, wl, rpk, g, e->uniq, n_frames, stream);
-    STAGE("post");
     const int radius = e->params.smoothing_radius, iters = e->params.smoothing_iterations;
     const bool smooth = radius > 0 && iters > 0;  // disparity.cu:73
     const size_t tight_step = (size_t)g.w * 2, tight_fs = g.npx * 2;
-    if (!smooth) {
-        launch_post(wl, rpk, gl, out, out_step, out_frame_stride, g, n_frames, stream);
-    } else {
-        launch_post(wl, rpk, gl, ta, tight_step, tight_fs, g, n_frames, stream);
-        STAGE("interpolate");
-        // disparity.hpp:27-28: minDisparity = cfg*16, maxDisparity = image width (not x16)
-        const int min16 = e->params.min_disparity * 16, maxd = g.w;
-        int16_t *src = ta, *dst = tb;
-        for (int it = 0; it < iters; ++it) {
-            const bool last = it == iters - 1;
-            if (last) launch_interpolate(src, tight_step, tight_fs, out, out_step, out_frame_stride, g.w, g.h, radius, min16, maxd, n_frames, stream);
-            else launch_interpolate(src, tight_step, tight_fs, dst, tight_step, tight_fs, g.w, g.h, radius, min16, maxd, n_frames, stream);
-            std::swap(src, dst);
+    // Enqueues every stage for frames [f0, f0+n) of this call on stream `st`.
+    auto enqueue = [&](int f0, int n, hipStream_t st, bool timed) {
+        const size_t s0 = (size_t)l.s0 + f0;
+        uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
+        uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
+        uint8_t *slabs = e->slabs + s0 * g.P * g.slab_bytes;
+        uint16_t *wl = e->wta_l + s0 * g.npx;
+        uint32_t *rpk = e->right_pk + s0 * g.npx;
+        int16_t *ta = e->tmp_a + s0 * g.npx, *tb = e->tmp_b + s0 * g.npx;
+        int16_t *o = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(out) + (size_t)f0 * out_frame_stride);
+        hipStream_t stream = st;  // STAGE records on the stream the kernels are launched on
+        TimingRec *rec_save = rec;
+        if (!timed) rec = nullptr;
+        STAGE("census");
+        ImageBatch lb{left + (size_t)f0 * left_frame_stride, left_step, left_frame_stride};
+        ImageBatch rb{right + (size_t)f0 * right_frame_stride, right_step, right_frame_stride};
+        launch_census(lb, rb, channels, n, gl, gr, cl, cr, rpk, g, st);
+        STAGE("aggregate");
+        AggArgs a = e->agg;
+        a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
+        launch_aggregate(a, n, st);
+        STAGE("wta");
+        launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
+        STAGE("post");
+        if (!smooth) {
+            launch_post(wl, rpk, gl, o, out_step, out_frame_stride, g, n, st);
+        } else {
+            launch_post(wl, rpk, gl, ta, tight_step, tight_fs, g, n, st);
+            STAGE("interpolate");
+            // disparity.hpp:27-28: minDisparity = cfg*16, maxDisparity = image width (not x16)
+            const int min16 = e->params.min_disparity * 16, maxd = g.w;
+            int16_t *src = ta, *dst = tb;
+            for (int it = 0; it < iters; ++it) {
+                const bool last = it == iters - 1;
+                if (last) launch_interpolate(src, tight_step, tight_fs, o, out_step, out_frame_stride, g.w, g.h, radius, min16, maxd, n, st);
+                else launch_interpolate(src, tight_step, tight_fs, dst, tight_step, tight_fs, g.w, g.h, radius, min16, maxd, n, st);
+                std::swap(src, dst);
+            }
         }
-    }
-    if (rec) {
-        (void)hipEventRecord(rec->ev[nt], stream);
-        std::lock_guard<std::mutex> lk(e->mu);
-        rec->n = nt;
+        if (rec) {
+            (void)hipEventRecord(rec->ev[nt], st);
+            std::lock_guard<std::mutex> lk(e->mu);
+            rec->n = nt;
+        }
+        rec = rec_save;
+    };
+    const int chunks = std::min(e->chunks, n_frames);
+    if (chunks <= 1) {
+        enqueue(0, n_frames, stream, true);
+    } else {
+        // software pipeline over sub-batches on two internal streams: the VALU-bound path aggregation of
+        // one chunk overlaps the HBM-bound winner-takes-all of the previous one
+        (void)hipEventRecord(e->ev_fork, stream);
+        for (int s = 0; s < 2; ++s) (void)hipStreamWaitEvent(e->aux[s], e->ev_fork, 0);
+        int f0 = 0;
+        for (int c = 0; c < chunks; ++c) {
+            const int n = (n_frames - f0) / (chunks - c);
+            enqueue(f0, n, e->aux[c & 1], c == 0);
+            f0 += n;
+        }
+        for (int s = 0; s < 2; ++s) {
+            (void)hipEventRecord(e->ev_join[s], e->aux[s]);
+            (void)hipStreamWaitEvent(stream, e->ev_join[s], 0);
+        }
     }
     hipError_t err = hipGetLastError();
     release(l);

@@ -60,18 +60,21 @@ __device__ __forceinline__ void store_u8s(uint8_t *p, const uint32_t (&v)[N]) {
     }
 }
 
+// slab bytes are read exactly once (by the WTA): non-temporal loads keep them from displacing reusable lines
 template <int N>
 __device__ __forceinline__ void load_u8s_add(const uint8_t *p, uint32_t (&acc)[N]) {
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     if constexpr (N == 4) {
-        uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+        uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] += (v >> (8 * i)) & 0xffu;
     } else if constexpr (N == 8) {
-        uint2 v = *reinterpret_cast<const uint2 *>(p);
+        v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i] += (v.x >> (8 * i)) & 0xffu; acc[4 + i] += (v.y >> (8 * i)) & 0xffu; }
     } else {
-        uint4 v = *reinterpret_cast<const uint4 *>(p);
+        v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[i] += (v.x >> (8 * i)) & 0xffu; acc[4 + i] += (v.y >> (8 * i)) & 0xffu;
@@ -214,8 +217,15 @@ __device__ __forceinline__ void load_census(const uint32_t *pl, const uint32_t *
     load_u32s<16>(pr, c.r);
 }
 
+// x[k] = left feature ^ right feature k: consumes the loaded registers right away so that the next
+// prefetch can land in them while the rest of the step runs
+__device__ __forceinline__ void agg_xor(const CensusRegs &c, uint32_t (&xr)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xr[k] = c.fl ^ c.r[k];
+}
+
 template <int LPP>
-__device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const CensusRegs &c, uint32_t sel_lo,
+__device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&xr)[16], uint32_t sel_lo,
                                          uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, uint8_t *po) {
     // matching cost minus the running minimum, packed like the state: cm[i] = (C[d0+i]-m, C[d0+i+8]-m)
     uint32_t negm = 0u - (mm & 0xffffu);
@@ -223,8 +233,8 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const C
     uint32_t cm[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint32_t clo = (uint32_t)__builtin_popcount(c.fl ^ c.r[15 - i]) + negm;
-        const uint32_t chi = (uint32_t)__builtin_popcount(c.fl ^ c.r[7 - i]) + negm;
+        const uint32_t clo = (uint32_t)__builtin_popcount(xr[15 - i]) + negm;
+        const uint32_t chi = (uint32_t)__builtin_popcount(xr[7 - i]) + negm;
         cm[i] = perm(chi, clo, 0x05040100u);
     }
     const uint32_t mp2 = pk_add(mm, p2p2);
@@ -246,7 +256,16 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const C
     uint4 o;
     o.x = perm(q23, q01, 0x05040100u); o.y = perm(q67, q45, 0x05040100u);
     o.z = perm(q23, q01, 0x07060302u); o.w = perm(q67, q45, 0x07060302u);
-    *reinterpret_cast<uint4 *>(po) = o;
+#ifdef CART_ABLATE_STORE  // timing experiment only: keep the bytes live, skip the slab store
+    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+    (void)po;
+#else
+    {   // write-once streaming data: non-temporal so the slabs do not evict the census planes from L2
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u q = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(q, reinterpret_cast<v4u *>(po));
+    }
+#endif
     // min over the pixel's D disparities, replicated into both halves
     uint32_t x = pk_min(pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3])), pk_min(pk_min(n[4], n[5]), pk_min(n[6], n[7])));
     x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
@@ -322,6 +341,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     uint32_t mm = 0;
     CensusRegs ca, cb;
 
+    // NOTE on the loop shapes below.  vmcnt retires in issue order and counts stores too, so a load issued
+    // AFTER a slab store cannot be consumed before that store has been written back (>1 us under write
+    // pressure).  Each step therefore issues the loads of step t+2 BEFORE its own store, consumes the loads
+    // of step t+1 after it, and keeps every VMEM instruction of the main loops unconditional (prefetches past
+    // the last step read valid padding / slack) so that the compiler can use exact counted vmcnt waits.
     if (dy == 0) {
         // ---- horizontal scans: the wave's pixels sit on P different rows, nothing to share; per-lane loads.
         // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
@@ -333,18 +357,29 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
         const uint32_t *pr = cen_r + (size_t)y * g.cpitch + g.cpadl + x - g.min_disp - d0 - 15;
         uint8_t *po = slab + ((size_t)y * g.w + x) * g.D + d0;
         const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
+        uint32_t xr[16];
         load_census(pl, pr, ca);
+        load_census(pl + cstride, pr + cstride, cb);
         int t = 0;
         for (; t + 1 < t1; t += 2) {
-            pl += cstride; pr += cstride;
-            load_census(pl, pr, cb);  // prefetch the next pixel's features while this one is reduced
-            agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
-            po += ostride;
-            if (t + 2 < t1) { pl += cstride; pr += cstride; load_census(pl, pr, ca); }
-            agg_step<LPP>(st, mm, cb, sel_lo, sel_hi, p1p1, p2p2, po);
-            po += ostride;
+            agg_xor(ca, xr);
+            __builtin_amdgcn_sched_barrier(0);
+            load_census(pl + 2 * cstride, pr + 2 * cstride, ca);  // step t+2 (reads row padding past the end)
+            __builtin_amdgcn_sched_barrier(0);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            __builtin_amdgcn_sched_barrier(0);
+            agg_xor(cb, xr);
+            __builtin_amdgcn_sched_barrier(0);
+            load_census(pl + 3 * cstride, pr + 3 * cstride, cb);  // step t+3
+            __builtin_amdgcn_sched_barrier(0);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po + ostride);
+            __builtin_amdgcn_sched_barrier(0);
+            pl += 2 * cstride; pr += 2 * cstride; po += 2 * ostride;
         }
-        if (t < t1) agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
+        if (t < t1) {
+            agg_xor(ca, xr);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+        }
         return;
     }
 
@@ -355,14 +390,18 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     if (dx > 0) { t0 = max(0, -j); t1 = min(g.h, g.w - j); }
     else if (dx < 0) { t0 = max(0, j - g.w + 1); t1 = min(g.h, j + 1); }
     else { t0 = 0; t1 = g.h; }
-    if (line >= nlines) { t0 = 0; t1 = 0; }
-    // wave-uniform step range = union over the wave's (adjacent) lines
-    const int jf = a.dirs[di].jmin + line0, jl = a.dirs[di].jmin + min(line0 + P, nlines) - 1;
-    int tb, te;
-    if (dx > 0) { tb = max(0, -jl); te = min(g.h, g.w - jf); }
-    else if (dx < 0) { tb = max(0, jf - g.w + 1); te = min(g.h, jl + 1); }
-    else { tb = 0; te = g.h; }
+    const bool valid_line = line < nlines;
+    if (!valid_line) { t0 = 0; t1 = 0; }
+    // wave-uniform ranges: [tb, te) = union of the wave's (adjacent) lines, [tm0, tm1) = steps on which
+    // every lane group of the wave is active (empty when the wave holds lines past the last one)
+    const int nv = min(P, nlines - line0);  // valid lines in this wave
+    const int jf = a.dirs[di].jmin + line0, jl = jf + nv - 1;
+    int tb, te, tm0, tm1;
+    if (dx > 0) { tb = max(0, -jl); te = min(g.h, g.w - jf); tm0 = max(0, -jf); tm1 = min(g.h, g.w - jl); }
+    else if (dx < 0) { tb = max(0, jf - g.w + 1); te = min(g.h, jl + 1); tm0 = max(0, jl - g.w + 1); tm1 = min(g.h, jf + 1); }
+    else { tb = 0; te = g.h; tm0 = 0; tm1 = g.h; }
     if (tb >= te) return;
+    if (nv < P || tm0 >= tm1) { tm0 = te; tm1 = te; }  // everything through the ragged path
 
     // cooperative window load: LDS slot l = 64*i + lane  <-  window dword 16*(l/20) + min(l%20, 15)
     int goff[WN::NLD];
@@ -379,52 +418,74 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
     uint32_t *buf0 = &s_win[wid][0][0], *buf1 = &s_win[wid][1][0];
 
-    // pointers at step tb; x of the wave's first line / of this lane's line
-    const int yb = ys + dy * tb;
-    const int xf = jf + dx * tb, xo = j + dx * tb;
-    const uint32_t *pw = cen_r + (size_t)yb * g.cpitch + g.cpadl + xf - g.min_disp - (WN::D - 1);  // window start
-    const uint32_t *pl = cen_l + (size_t)yb * g.cpitch + g.cpadl + xo;
+    // pointers as a function of the step t
     const ptrdiff_t cstride = (ptrdiff_t)dy * g.cpitch + dx;
-    uint8_t *po = slab + ((ptrdiff_t)yb * g.w + xo) * g.D + d0;
     const ptrdiff_t ostride = ((ptrdiff_t)dy * g.w + dx) * g.D;
+    const uint32_t *pw_base = cen_r + (ptrdiff_t)ys * g.cpitch + g.cpadl + jf - g.min_disp - (WN::D - 1);  // window start at t = 0
+    const uint32_t *pl_base = cen_l + (ptrdiff_t)ys * g.cpitch + g.cpadl + j;
+    uint8_t *po_base = slab + ((ptrdiff_t)ys * g.w + j) * g.D + d0;
 
-    uint32_t gw[WN::NLD];
+    // ragged start / end of diagonal lines (and waves with invalid lines): simple, fully synchronous steps
+    auto ragged = [&](int ta, int tz) {
+        for (int t = ta; t < tz; ++t) {
+            const uint32_t *pw = pw_base + t * cstride;
 #pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
-    ca.fl = *pl;
-    int t = tb;
-    for (; t + 1 < te; t += 2) {
-        pw += cstride; pl += cstride;
+            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
+            if (t >= t0 && t < t1) {
+                uint32_t xr[16];
+                ca.fl = pl_base[t * cstride];
+                win_read<LPP>(buf0, base_slot, xslot, ca.r);
+                agg_xor(ca, xr);
+                agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po_base + t * ostride);
+            }
+        }
+    };
+    ragged(tb, tm0);
+    if (tm0 < tm1) {
+        const uint32_t *pw = pw_base + tm0 * cstride, *pl = pl_base + tm0 * cstride;
+        uint8_t *po = po_base + tm0 * ostride;
+        uint32_t g0[WN::NLD], g1[WN::NLD], f0, f1;
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) gw[i] = pw[goff[i]];  // window of step t+1, in flight during step t
-        cb.fl = *pl;
-        if (t >= t0 && t < t1) {
+        for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
+        f0 = *pl;
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) g1[i] = pw[cstride + goff[i]];  // step tm0+1
+        f1 = pl[cstride];
+        uint32_t xr[16];
+        int t = tm0;
+        for (; t + 1 < tm1; t += 2) {
+#pragma unroll
+            for (int i = 0; i < WN::NLD; ++i) g0[i] = pw[2 * cstride + goff[i]];  // step t+2, issued before this step's store
+            ca.fl = f0;
+            f0 = pl[2 * cstride];
+            __builtin_amdgcn_sched_barrier(0);
             win_read<LPP>(buf0, base_slot, xslot, ca.r);
-            agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
-        }
-        po += ostride;
+            agg_xor(ca, xr);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = gw[i];
-        if (t + 2 < te) {
-            pw += cstride; pl += cstride;
+            for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = g1[i];        // window of step t+1
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) gw[i] = pw[goff[i]];
-            ca.fl = *pl;
-        }
-        if (t + 1 >= t0 && t + 1 < t1) {
+            for (int i = 0; i < WN::NLD; ++i) g1[i] = pw[3 * cstride + goff[i]];  // step t+3
+            cb.fl = f1;
+            f1 = pl[3 * cstride];
+            __builtin_amdgcn_sched_barrier(0);
             win_read<LPP>(buf1, base_slot, xslot, cb.r);
-            agg_step<LPP>(st, mm, cb, sel_lo, sel_hi, p1p1, p2p2, po);
-        }
-        po += ostride;
-        if (t + 2 < te) {
+            agg_xor(cb, xr);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po + ostride);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = gw[i];
+            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = g0[i];        // window of step t+2
+            pw += 2 * cstride; pl += 2 * cstride; po += 2 * ostride;
+        }
+        if (t < tm1) {
+            ca.fl = f0;
+            win_read<LPP>(buf0, base_slot, xslot, ca.r);
+            agg_xor(ca, xr);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
         }
     }
-    if (t < te && t >= t0 && t < t1) {
-        win_read<LPP>(buf0, base_slot, xslot, ca.r);
-        agg_step<LPP>(st, mm, ca, sel_lo, sel_hi, p1p1, p2p2, po);
-    }
+    ragged(tm1, te);
 }
 
 int agg_lines_per_block(int D) { return 256 / (D / 16); }
