@@ -502,66 +502,104 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ winner takes all
-// Block = 64 pixels of one row, 16-lane row per pixel (4 passes of 16 pixels).  The summed
-// costs of the tile live in LDS as u16 [64][D] so that (a) the sub-pixel neighbours and
-// (b) the right-view diagonal minima S(p+d, d) come from LDS; per-tile right minima are
-// merged across tiles with one packed atomicMin per right pixel and tile.
-template <int DPL>
+// Block = 64 pixels of one row; a pixel is owned by LPP = D/16 lanes, 16 disparities per lane as 8
+// packed u16 pairs s[k] = (S[d0+2k], S[d0+2k+1]).  Per path one 16-byte non-temporal load per lane, the
+// bytes are widened by v_perm_b32 and summed with v_pk_add_u16 (1 VALU op per cell and path).
+//   * argmin (ties -> lowest d, oracle S5): packed keys S*16 + local index, packed min tree, then one
+//     32-bit key (S<<16 | d) per lane reduced over the pixel's lanes by DPP;
+//   * uniqueness: (float)S*u >= (float)best is monotone in S, so it equals S >= T for the integer
+//     threshold T = min{s : (float)s*u >= (float)best}; the pixel is unique iff every S[d] < T lies within
+//     |d - best| <= 1, i.e. iff sum_d max(T-S[d],0) equals the same sum over the three neighbours;
+//   * the summed costs of the tile live in LDS as u16 [64][D]: sub-pixel neighbours and the right-view
+//     diagonal minima S(p+d, d) (oracle S6) come from there; per-tile right minima are merged across tiles
+//     with one packed atomicMin per right pixel and tile.
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+// smallest s with (float)s*u >= (float)bc, clamped to 4095 (> any reachable cost sum, <= 8*255)
+__device__ __forceinline__ uint32_t uniq_threshold(uint32_t bc, float u) {
+    if (bc == 0) return 0;
+    if (!(u > 0.f)) return 4095u;
+    const float bcf = (float)bc;
+    const float q = bcf / u;
+    if (q > 4000.f) return 4095u;
+    const int g = (int)q;
+    int T = g + 3;
+#pragma unroll
+    for (int c = 2; c >= -2; --c) {
+        const int v = g + c;
+        if (v >= 0 && (float)v * u >= bcf) T = v;
+    }
+    return (uint32_t)min(T, 4095);
+}
+
+template <int LPP>
 __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                                                   Geometry g, float uniq) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lds[];  // [kWtaTileX][D]
-    constexpr int D = DPL * 16;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr int D = LPP * 16;
+    constexpr int PPP = 256 / LPP;            // pixels per pass
+    constexpr int NPASS = kWtaTileX / PPP;    // 1 (D=64), 2 (D=128), 4 (D=256)
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
-    const int grp = threadIdx.x >> 4, lane16 = threadIdx.x & 15, d0 = lane16 * DPL;
-    const int row_in_wave = (threadIdx.x & 63) >> 4;
+    const int grp = threadIdx.x / LPP, gl = threadIdx.x % LPP, d0 = gl * 16;
 
-    uint32_t pk_res[4];
-    bool uniq_res[4];
+    uint32_t pk_res[NPASS], tot_res[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int xl = pass * 16 + grp;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int xl = pass * PPP + grp;
         const int xc = min(x0 + xl, g.w - 1);
-        uint32_t S[DPL];
+        uint32_t sm[8];
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) S[k] = 0;
+        for (int k = 0; k < 8; ++k) sm[k] = 0;
         const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xc) * D + d0;
-        for (int r = 0; r < g.P; ++r) load_u8s_add<DPL>(p + (size_t)r * g.slab_bytes, S);
-        uint16_t *dst = s_lds + xl * D + d0;
+        for (int r = 0; r < g.P; ++r) {
+            const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)r * g.slab_bytes));
 #pragma unroll
-        for (int k = 0; k < DPL; k += 2)
-            *reinterpret_cast<uint32_t *>(dst + k) = S[k] | (S[k + 1] << 16);
-        uint32_t pk = 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) pk = min(pk, (S[k] << 16) | (uint32_t)(d0 + k));
-        pk = row_allmin(pk);
-        const uint32_t bc = pk >> 16;
-        const int bd = (int)(pk & 0xffffu);
-        const float bcf = (float)bc;
-        bool fail = false;
-#pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-            const float lhs = (float)S[k] * uniq;
-            const bool u1 = lhs >= bcf;
-            const bool u2 = abs(d0 + k - bd) <= 1;
-            fail |= !(u1 || u2);
+            for (int q = 0; q < 4; ++q) {
+                sm[2 * q] = pk_add(sm[2 * q], perm(0u, v[q], 0x0c010c00u));
+                sm[2 * q + 1] = pk_add(sm[2 * q + 1], perm(0u, v[q], 0x0c030c02u));
+            }
         }
-        const unsigned long long bal = __ballot(fail);
-        uniq_res[pass] = ((bal >> (16 * row_in_wave)) & 0xffffull) == 0ull;
+        v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * D + d0);
+        dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
+        dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
+        // packed argmin keys: S*16 + (2k | 2k+1)
+        uint32_t key[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
+            key[k] = __builtin_bit_cast(uint32_t, kk);
+        }
+        uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
+        m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
+        uint32_t pk = ((m >> 4) << 16) | (uint32_t)(d0 + (int)(m & 15u));
+        pk = group_allmin<LPP>(pk);
+        const uint32_t T = uniq_threshold(pk >> 16, uniq);
+        const uint32_t tt = T * 0x10001u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
+        tot_res[pass] = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         pk_res[pass] = pk;
     }
     __syncthreads();
 
-    if (lane16 == 0) {
+    if (gl == 0) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int xl = pass * 16 + grp, x = x0 + xl;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int xl = pass * PPP + grp, x = x0 + xl;
             if (x >= g.w) continue;
+            const int bd = (int)(pk_res[pass] & 0xffffu), bc = (int)(pk_res[pass] >> 16);
+            const int T = (int)uniq_threshold((uint32_t)bc, uniq);
+            const uint16_t *srow = s_lds + xl * D;
+            const int l = bd > 0 ? srow[bd - 1] : 0x7fff, r = bd < D - 1 ? srow[bd + 1] : 0x7fff;
+            const int tot_nbr = max(T - bc, 0) + max(T - l, 0) + max(T - r, 0);
             uint32_t out = kWtaInvalid;
-            if (uniq_res[pass]) {
-                const int bd = (int)(pk_res[pass] & 0xffffu), bc = (int)(pk_res[pass] >> 16);
+            if ((int)tot_res[pass] == tot_nbr) {
                 int subp = bd * 16;
                 if (bd > 0 && bd < D - 1) {
-                    const int l = s_lds[xl * D + bd - 1], r = s_lds[xl * D + bd + 1];
                     const int num = l - r, den = l - 2 * bc + r;
                     if (den != 0) subp += (num * 16 + den) / (2 * den);
                 }
@@ -577,10 +615,15 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
         if (p < 0 || p >= g.w) continue;
         const int xa = max(x0, p), xb = min(min(x0 + kWtaTileX, p + D), g.w);
         uint32_t best = 0xffffffffu;
-        for (int x = xa; x < xb; ++x) {
-            const int d = x - p;
-            best = min(best, ((uint32_t)s_lds[(x - x0) * D + d] << 16) | (uint32_t)d);
+        int x = xa;
+        const uint16_t *sp = s_lds + (x - x0) * D + (x - p);
+        for (; x + 3 < xb; x += 4, sp += 4 * (D + 1)) {
+            const uint32_t d = (uint32_t)(x - p);
+            const uint32_t k0 = ((uint32_t)sp[0] << 16) | d, k1 = ((uint32_t)sp[D + 1] << 16) | (d + 1);
+            const uint32_t k2 = ((uint32_t)sp[2 * (D + 1)] << 16) | (d + 2), k3 = ((uint32_t)sp[3 * (D + 1)] << 16) | (d + 3);
+            best = min(min(best, min(k0, k1)), min(k2, k3));
         }
+        for (; x < xb; ++x, sp += D + 1) best = min(best, ((uint32_t)sp[0] << 16) | (uint32_t)(x - p));
         if (xa < xb) atomicMin(&right_pk[(size_t)frame * g.npx + (size_t)y * g.w + p], best);
     }
 }
