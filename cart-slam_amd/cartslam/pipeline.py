@@ -86,10 +86,10 @@ class StereoPipeline:
             per_frame = [self.schedule.params] * n
         else:
             if self.world > 1:
-                allh = torch.empty((self.world, n, 256), dtype=torch.int32, device=left.device)
+                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=left.device)
                 torch.distributed.all_gather_into_tensor(allh, self._hist, group=self.group)
                 # [rank][k] -> id order k*world + rank
-                hists = allh.permute(1, 0, 2).reshape(n * self.world, 256).cpu().numpy()
+                hists = allh.view(self.world, n, 256).permute(1, 0, 2).reshape(n * self.world, 256).cpu().numpy()
             else:
                 hists = self._hist.cpu().numpy()
             allp = self.schedule.advance(self.next_id, hists)

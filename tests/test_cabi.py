@@ -1,0 +1,69 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/cart_engine.h
+declares (no compute calls -- there is no GPU here), and its HOST entry points agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cart_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cart_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cartslam import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in include/cart_engine.h but not exported"
+    assert set(syms) == set(_lib.PROTOTYPES), "python prototypes out of sync with the header"
+    assert lib.cart_engine_version().decode().startswith("cart_engine gfx950")
+
+
+def test_struct_layouts_match_header():
+    from cartslam import _lib
+    assert C.sizeof(_lib.EngineParams) == 12 * 4 and C.sizeof(_lib.PlaneParams) == 6 * 4
+    p = _lib.EngineParams()
+    _lib.load().cart_engine_default_params(C.byref(p))
+    # reference defaults: cartconfig.cpp:144-152, disparity.hpp:32, cartslam.hpp:4
+    assert (p.min_disparity, p.num_disparities, p.paths, p.p1, p.p2) == (4, 256, 4, 10, 120)
+    assert (p.uniqueness_ratio, p.smoothing_radius, p.smoothing_iterations, p.max_inflight) == (12, -1, 5, 12)
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_params():
+    import torch
+    from cartslam import Engine, EngineError
+    with pytest.raises(EngineError):
+        Engine(100, 50, num_disparities=100)  # validated before any device call
+    if not torch.cuda.is_available():
+        with pytest.raises(EngineError):
+            Engine(100, 50, num_disparities=64)  # no device: must raise, never fall back to a CPU path
+
+
+def test_host_peak_finder_matches_oracle():
+    from cartslam import find_peaks, find_plane_params
+    rng = np.random.default_rng(9)
+    for k in range(60):
+        if k % 3 == 0:
+            hh = rng.integers(0, 40, 256)
+        elif k % 3 == 1:
+            hh = rng.integers(0, 5, 256) * rng.integers(0, 3000, 256)
+        else:  # smooth two-peak shapes like real derivative histograms
+            x = np.arange(256)
+            hh = 5000 * np.exp(-0.5 * ((x - 128) / rng.uniform(1, 4)) ** 2) + 2000 * np.exp(-0.5 * ((x - rng.integers(132, 150)) / rng.uniform(1, 5)) ** 2)
+            hh = hh + rng.integers(0, 30, 256)
+        hh = hh.astype(np.int32)
+        assert find_peaks(hh) == O.find_peaks(hh)
+        prev = tuple(int(v) for v in rng.integers(-20, 20, 6))
+        ok, p = find_plane_params(hh, prev)
+        eok, ep = O.histogram_peak_params(hh, prev)
+        assert ok == eok and p.as_tuple() == ep

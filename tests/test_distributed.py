@@ -1,0 +1,114 @@
+"""World-size-2 gloo tests (CPU) of the frame-sharded path: id interleaving, the histogram all-gather and the
+plane-parameter schedule must give every rank exactly what one process gets feeding the frames in id order.
+The per-frame histograms stand in for the GPU's (they come from the oracle here; the GPU parity of the histogram
+kernel itself is covered in test_gpu_parity.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from cartslam.pipeline import PlaneParameterSchedule, shard_ids
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def make_hists(n, seed=3):
+    """n synthetic per-frame derivative histograms whose peaks drift so that parameters really change."""
+    rng = np.random.default_rng(seed)
+    x = np.arange(256)
+    out = []
+    for f in range(n):
+        h = 6000 * np.exp(-0.5 * ((x - 128) / 1.5) ** 2) + 2500 * np.exp(-0.5 * ((x - (136 + f // 20)) / 2.5) ** 2)
+        out.append((h + rng.integers(0, 20, 256)).astype(np.int32))
+    return np.stack(out)
+
+
+def sequential_reference(hists, update_interval, reset_interval):
+    """The reference's bookkeeping, one frame at a time (planeseg.cu:271-283, :381-395) with the oracle's peak finder."""
+    cum = np.zeros(256, np.int64)
+    params = (0, 0, 0, 0, 0, 0)
+    out = []
+    for k, h in enumerate(hists):
+        fid = k + 1
+        cum += h
+        if fid % update_interval == 1:
+            h32 = cum.astype(np.int32)
+            if fid % (update_interval * reset_interval) == 1:
+                cum[:] = 0
+            _, params = O.histogram_peak_params(h32, params)
+        out.append(params)
+    return out
+
+
+def test_schedule_matches_sequential_reference():
+    hists = make_hists(95)
+    for ui, ri in ((30, 10), (7, 2), (4, 3)):
+        exp = sequential_reference(hists, ui, ri)
+        sch = PlaneParameterSchedule("histogram_peak", update_interval=ui, reset_interval=ri)
+        got = []
+        for a in range(0, 95, 16):  # arbitrary batch boundaries must not matter
+            got += [p.as_tuple() for p in sch.advance(a + 1, hists[a:a + 16])]
+        assert got == exp
+
+
+def test_static_provider_and_unknown_type():
+    sch = PlaneParameterSchedule("static", static_params=(6, 18, -5, 6, 12, 0))
+    assert [p.as_tuple() for p in sch.advance(1, make_hists(3))] == [(6, 18, -5, 6, 12, 0)] * 3
+    with pytest.raises(ValueError):
+        PlaneParameterSchedule("nope")
+
+
+def test_shard_ids_partition():
+    world, n_local, first = 4, 5, 17
+    ids = sorted(i for r in range(world) for i in shard_ids(first, n_local, r, world))
+    assert ids == list(range(first, first + world * n_local))
+
+
+def _worker(rank, world, port, n_local, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hists = make_hists(world * n_local * steps)
+        sch = PlaneParameterSchedule("histogram_peak", update_interval=7, reset_interval=2)
+        mine = []
+        next_id = 1
+        for s in range(steps):
+            ids = shard_ids(next_id, n_local, rank, world)
+            local = torch.from_numpy(np.stack([hists[i - 1] for i in ids]))
+            allh = torch.empty((world * n_local, 256), dtype=torch.int32)
+            dist.all_gather_into_tensor(allh, local)  # the path's only exchange step
+            ordered = allh.view(world, n_local, 256).permute(1, 0, 2).reshape(n_local * world, 256).numpy()
+            allp = sch.advance(next_id, ordered)
+            mine += [(i, p.as_tuple()) for i, p in zip(ids, allp[rank::world])]
+            next_id += n_local * world
+        q.put((rank, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_equals_single_process():
+    world, n_local, steps = 2, 5, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = sequential_reference(make_hists(world * n_local * steps), 7, 2)
+    seen = {}
+    for _, mine in results:
+        for fid, params in mine:
+            seen[fid] = params
+    assert sorted(seen) == list(range(1, world * n_local * steps + 1))
+    for fid, params in seen.items():
+        assert params == exp[fid - 1], f"frame {fid}"

@@ -213,16 +213,6 @@ def test_ccl_hard_shapes(torch_cuda):
     eng.close()
 
 
-def test_host_peak_finder_matches_oracle():
-    from cartslam import find_peaks, find_plane_params
-    rng = np.random.default_rng(9)
-    for k in range(40):
-        hh = (rng.integers(0, 40, 256) if k % 2 else rng.integers(0, 5, 256) * rng.integers(0, 3000, 256)).astype(np.int32)
-        assert find_peaks(hh) == O.find_peaks(hh)
-        prev = tuple(int(v) for v in rng.integers(-20, 20, 6))
-        ok, p = find_plane_params(hh, prev)
-        eok, ep = O.histogram_peak_params(hh, prev)
-        assert ok == eok and p.as_tuple() == ep
 
 
 def test_golden_fixtures(torch_cuda):
@@ -299,4 +289,41 @@ def test_full_size_properties_1080p_d256(torch_cuda):
     both = eng.compute_disparity(torch.stack([tl, tl]), torch.stack([tr, tr])).cpu().numpy()
     assert (both[0] == a).all() and (both[1] == a).all()
     assert ((a >= (md - 1) * 16) & (a < (md + D) * 16)).all()
+    eng.close()
+
+
+def test_batched_pipeline_matches_frame_by_frame_oracle(torch_cuda):
+    """Whole hot path through the batched driver (disparity -> plane derivative + histogram -> plane-parameter
+    schedule -> classify -> CCL) against the oracle fed the same frames one at a time in id order, i.e. what the
+    reference's two modules would produce (disparity.cu:49-80, planeseg.cu:246-403)."""
+    torch = torch_cuda
+    from cartslam.pipeline import StereoPipeline
+    w, h, D, P, n = 256, 96, 64, 8, 7
+    ui, ri = 3, 2
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=4)
+    pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True)
+    ls, rs = synth.make_batch(n, w, h, D, 4, seed=99)
+    outs = []
+    for a in range(0, n, 4):  # batches of 4, then 3
+        o = pipe.process_batch(dev(torch, ls[a:a + 4]), dev(torch, rs[a:a + 4]))
+        outs.append({k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in o.items()})
+    disp = np.concatenate([o["disparity"] for o in outs]); planes = np.concatenate([o["planes"] for o in outs])
+    ids = np.concatenate([o["ids"] for o in outs]); ncomp = np.concatenate([o["n_components"] for o in outs])
+    cum = np.zeros(256, np.int64)
+    params = (0, 0, 0, 0, 0, 0)
+    for f in range(n):
+        fid = f + 1
+        ed = O.disparity_module(ls[f], rs[f], D, P, 4, radius=2, iterations=1)
+        assert (disp[f] == ed).all(), f"disparity frame {fid}"
+        dd, hist = O.plane_derivative(ed)
+        cum += hist
+        if fid % ui == 1:
+            h32 = cum.astype(np.int32)
+            if fid % (ui * ri) == 1:
+                cum[:] = 0
+            _, params = O.histogram_peak_params(h32, params)
+        ep = O.classify(dd, params)
+        assert (planes[f] == ep).all(), f"planes frame {fid}"
+        eids, en = O.ccl(ep)
+        assert (ids[f] == eids).all() and ncomp[f] == en, f"ccl frame {fid}"
     eng.close()
