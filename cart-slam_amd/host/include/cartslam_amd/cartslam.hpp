@@ -1,0 +1,77 @@
+// cartslam.hpp -- minimal System / SystemRunData able to drive modules exactly like the reference's
+// (include/cartslam.hpp:3-5,27-117, src/cartslam.cpp:60-334): per-frame blackboard, dependency wait, one
+// future per module, bounded number of frames in flight, run retention ring.  Scheduling details that are
+// not on the arithmetic path (cross-frame runOffset waits, out-of-order completion bookkeeping) are reduced
+// to what the three hot-path modules need.
+#pragma once
+
+#define CARTSLAM_RUN_RETENTION 32
+#define CARTSLAM_CONCURRENT_RUN_LIMIT 12
+
+#include <condition_variable>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "data.hpp"
+#include "datasource.hpp"
+#include "module.hpp"
+
+namespace cart {
+
+class System;
+
+class SystemRunData : public DataContainer {
+   public:
+    SystemRunData(uint32_t id, System *system, std::shared_ptr<DataElement> dataElement) : dataElement(dataElement), id(id), system(system) {}
+    std::shared_ptr<SystemRunData> getRelativeRun(const int8_t offset);
+    std::shared_ptr<DataElement> dataElement;
+    const uint32_t id;  // 1-based frame id (cartslam.cpp:194)
+
+   private:
+    System *system;
+};
+
+class System : public DataContainer {
+   public:
+    explicit System(std::shared_ptr<DataSource> dataSource, size_t runRetention = CARTSLAM_RUN_RETENTION,
+                    size_t concurrentRunLimit = CARTSLAM_CONCURRENT_RUN_LIMIT);
+    ~System();
+
+    // one frame: next data element, every module once (cartslam.cpp:228-334). The future resolves when all
+    // modules of the frame have finished; exceptions of modules propagate through it.
+    std::future<void> run();
+
+    template <typename T, typename... Args>
+    void addModule(Args... args) { addModule(std::make_shared<T>(args...)); }
+    void addModule(std::shared_ptr<SystemModule> module);
+
+    template <typename T>
+    std::shared_ptr<T> getModule() {
+        for (const auto &m : modules)
+            if (auto c = std::dynamic_pointer_cast<T>(m)) return c;
+        throw std::invalid_argument("Could not find module");
+    }
+
+    std::shared_ptr<SystemRunData> getRunById(const uint32_t id);
+    void insertGlobalData(const std::string &key, std::shared_ptr<void> data) { insertData(std::make_pair(key, data)); }
+    const std::shared_ptr<DataSource> getDataSource() const { return dataSource; }
+    const std::vector<std::shared_ptr<SystemModule>> &getModules() const { return modules; }
+
+   private:
+    void verifyDependencies();  // every required same-frame key has a provider (cartslam.cpp:74-90)
+
+    const size_t runRetention, concurrentRunLimit;
+    bool verifiedDependencies = false;
+    uint32_t runId = 0;
+    size_t activeRuns = 0;
+    std::shared_ptr<DataSource> dataSource;
+    std::vector<std::shared_ptr<SystemModule>> modules;
+    std::vector<std::shared_ptr<SystemRunData>> runs;
+    std::mutex runMutex;
+    std::condition_variable runCondition;
+};
+}  // namespace cart

@@ -1,0 +1,89 @@
+#include "cartslam_amd/cartslam.hpp"
+
+#include <algorithm>
+
+namespace cart {
+
+// src/modules/module.cpp:7-19: post runInternal to a worker and hand back its future
+std::future<system_data_t> SyncWrapperSystemModule::run(System &system, SystemRunData &data) {
+    return std::async(std::launch::async, [this, &system, &data]() { return this->runInternal(system, data); });
+}
+
+std::shared_ptr<SystemRunData> SystemRunData::getRelativeRun(const int8_t offset) {
+    if (offset > 0) throw std::invalid_argument("Offset must be negative or zero");
+    const int64_t target = (int64_t)id + offset;
+    if (target <= 0) throw std::invalid_argument("Index out of range");
+    return system->getRunById((uint32_t)target);
+}
+
+System::System(std::shared_ptr<DataSource> dataSource, size_t runRetention, size_t concurrentRunLimit)
+    : runRetention(runRetention), concurrentRunLimit(concurrentRunLimit), dataSource(dataSource) {}
+
+System::~System() {
+    std::unique_lock<std::mutex> lock(runMutex);
+    runCondition.wait(lock, [this] { return activeRuns == 0; });
+}
+
+void System::addModule(std::shared_ptr<SystemModule> module) { modules.push_back(module); }
+
+std::shared_ptr<SystemRunData> System::getRunById(const uint32_t id) {
+    std::unique_lock<std::mutex> lock(runMutex);
+    for (auto &r : runs)
+        if (r->id == id) return r;
+    throw std::invalid_argument("Index out of range");
+}
+
+void System::verifyDependencies() {
+    std::map<std::string, bool> provided;
+    for (const auto &m : modules)
+        for (const auto &k : m->getProvidedData()) provided[k] = true;
+    for (const auto &m : modules)
+        for (const auto &d : m->getRequiredData())
+            if (!d.optional && !provided.count(d.name)) throw std::invalid_argument("Module " + m->name + " requires \"" + d.name + "\" but no module provides it");
+    verifiedDependencies = true;
+}
+
+std::future<void> System::run() {
+    if (!verifiedDependencies) verifyDependencies();
+    std::shared_ptr<SystemRunData> run;
+    {
+        std::unique_lock<std::mutex> lock(runMutex);
+        runCondition.wait(lock, [this] { return activeRuns < concurrentRunLimit; });  // cartslam.cpp:196-198
+        auto element = dataSource->getNext();
+        run = std::make_shared<SystemRunData>(++runId, this, element);
+        runs.push_back(run);
+        if (runs.size() > runRetention) runs.erase(runs.begin());  // cartslam.cpp:202-205
+        ++activeRuns;
+    }
+    auto mods = modules;
+    return std::async(std::launch::async, [this, run, mods]() {
+        std::exception_ptr first;
+        std::vector<std::future<void>> done;
+        for (const auto &m : mods) {
+            // every module gets its own waiter: dependencies first (cartslam.cpp:96-167), then the module, then the
+            // returned (key, ptr) pairs go onto the frame's blackboard (cartslam.cpp:279-301)
+            done.push_back(std::async(std::launch::async, [this, run, m]() {
+                std::vector<std::string> same_frame;
+                for (const auto &d : m->getRequiredData()) {
+                    if (d.runOffset == 0) { same_frame.push_back(d.name); continue; }
+                    if ((int64_t)run->id + d.runOffset <= 0) continue;
+                    try { run->getRelativeRun(d.runOffset)->waitForData({d.name}); }
+                    catch (...) { if (!d.optional) throw; }
+                }
+                run->waitForData(same_frame);
+                system_data_t out = m->run(*this, *run).get();
+                for (const auto &kv : out) run->insertData(kv);
+            }));
+        }
+        for (auto &f : done) {
+            try { f.get(); } catch (...) { if (!first) first = std::current_exception(); }
+        }
+        {
+            std::unique_lock<std::mutex> lock(runMutex);
+            --activeRuns;
+        }
+        runCondition.notify_all();
+        if (first) std::rethrow_exception(first);
+    });
+}
+}  // namespace cart

@@ -1,0 +1,63 @@
+// cart_slam_amd <source.json> <modules.json> [--frames N] [--dump DIR] [--sequential 1]
+// (--sequential 1 finishes every frame before the next starts: the cumulative plane histogram then sees the frames in id
+//  order, which the reference's concurrent frame loop does not guarantee)
+// Frame loop of the reference's src/main.cpp:8-63 without logging/UI; --dump writes every frame's blackboard images as
+// raw little-endian files (<DIR>/<id>_<key>.bin) so that tests can compare them with the oracle.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "cartslam_amd/cartconfig.hpp"
+#include "cartslam_amd/modules/planeseg.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::cerr << "Usage: " << argv[0] << " <data source config file> <module config file> [--frames N] [--dump DIR]\n";
+        return 1;
+    }
+    int maxFrames = 1 << 30;
+    std::string dump;
+    bool sequential = false;
+    for (int i = 3; i + 1 < argc; i += 2) {
+        if (!std::strcmp(argv[i], "--frames")) maxFrames = std::atoi(argv[i + 1]);
+        else if (!std::strcmp(argv[i], "--dump")) dump = argv[i + 1];
+        else if (!std::strcmp(argv[i], "--sequential")) sequential = std::atoi(argv[i + 1]) != 0;
+    }
+    try {
+        auto dataSource = cart::config::readDataSourceConfig(argv[1]);
+        auto system = std::make_shared<cart::System>(dataSource);
+        cart::config::readModuleConfig(argv[2], system);
+        std::vector<std::future<void>> pending;
+        int frames = 0;
+        while (!dataSource->isFinished() && frames < maxFrames) {
+            if (!dataSource->isNextReady()) continue;
+            pending.push_back(system->run());
+            if (sequential) pending.back().wait();
+            ++frames;
+        }
+        int failed = 0;
+        for (auto &f : pending) {
+            try { f.get(); } catch (const std::exception &e) { std::cerr << "Error in processing: " << e.what() << "\n"; ++failed; }
+        }
+        if (!dump.empty()) {
+            const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
+                                  CARTSLAM_KEY_PLANE_COMPONENTS};
+            for (int id = 1; id <= frames; ++id) {
+                auto run = system->getRunById((uint32_t)id);
+                for (const char *k : keys) {
+                    if (!run->hasData(k)) continue;
+                    auto img = run->getData<cart::image_t>(k);
+                    auto bytes = img->downloadTight();
+                    std::ofstream o(dump + "/" + std::to_string(id) + "_" + k + ".bin", std::ios::binary);
+                    o.write(reinterpret_cast<const char *>(bytes.data()), (std::streamsize)bytes.size());
+                }
+            }
+        }
+        std::cout << "frames " << frames << " failed " << failed << "\n";
+        return failed ? 2 : 0;
+    } catch (const std::exception &e) {
+        std::cerr << "fatal: " << e.what() << "\n";
+        return 1;
+    }
+}

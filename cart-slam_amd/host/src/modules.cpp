@@ -1,0 +1,173 @@
+// modules.cpp -- the three hot-path modules on top of the C ABI (include/cart_engine.h).
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+
+#include "cartslam_amd/modules/disparity.hpp"
+#include "cartslam_amd/modules/planeseg.hpp"
+
+namespace cart {
+namespace {
+void hipCheck(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+struct ScopedStream {  // the reference creates one stream per invocation (disparity.cu:56, planeseg.cu:279-280)
+    hipStream_t s = nullptr;
+    ScopedStream() { hipCheck(hipStreamCreate(&s), "hipStreamCreate"); }
+    ~ScopedStream() { if (s) (void)hipStreamDestroy(s); }
+    void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+};
+
+cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int radius, int iterations, int paths, int p1, int p2, int uniq) {
+    cart_engine_params p;
+    cart_engine_default_params(&p);
+    p.width = res.width; p.height = res.height;
+    p.min_disparity = minDisparity; p.num_disparities = numDisparities; p.paths = paths; p.p1 = p1; p.p2 = p2;
+    p.uniqueness_ratio = uniq; p.smoothing_radius = radius; p.smoothing_iterations = iterations;
+    p.max_inflight = CARTSLAM_CONCURRENT_RUN_LIMIT;
+    return p;
+}
+}  // namespace
+
+EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
+    if (cart_engine_create(&params, &engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
+}
+EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }
+void EngineHandle::fail(const char *what) const { throw std::runtime_error(std::string(what) + ": " + cart_last_error(engine)); }
+
+// ---------------------------------------------------------------- disparity (disparity.cu:49-80)
+ImageDisparityModule::ImageDisparityModule(const Size imageRes, int minDisparity, int numDisparities, int /*blockSize: ignored by the CUDA SGM too*/,
+                                           int smoothingRadius, int smoothingIterations, int paths, int p1, int p2, int uniquenessRatio)
+    : SyncWrapperSystemModule("ImageDisparity") {
+    this->providesData.push_back(CARTSLAM_KEY_DISPARITY);
+    engine = std::make_shared<EngineHandle>(imageRes, paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio));
+}
+
+system_data_t ImageDisparityModule::runInternal(System &, SystemRunData &data) {
+    if (data.dataElement->type != DataElementType::STEREO) throw std::runtime_error("ImageDisparityModule requires StereoDataElement");
+    auto stereo = std::static_pointer_cast<StereoDataElement>(data.dataElement);
+    const image_t &l = stereo->left, &r = stereo->right;
+    const int channels = l.type() == CV_8UC3 ? 3 : 1;
+    if ((l.type() != CV_8UC3 && l.type() != CV_8UC1) || r.type() != l.type()) throw std::runtime_error("ImageDisparityModule requires CV_8UC1 or CV_8UC3 images");
+    ScopedStream stream;
+    auto disparity = std::make_shared<image_t>(l.rows, l.cols, CV_16SC1);
+    if (cart_compute_disparity(engine->get(), l.ptr<uint8_t>(), l.step, r.ptr<uint8_t>(), r.step, channels, disparity->ptr<int16_t>(), disparity->step, stream.s) != 0)
+        engine->fail("cart_compute_disparity");
+    stream.wait();  // stream.waitForCompletion(), disparity.cu:77
+    return MODULE_RETURN(CARTSLAM_KEY_DISPARITY, disparity);
+}
+
+// ---------------------------------------------------------------- derivative (derivative.cu:151-184)
+ImageDisparityDerivativeModule::ImageDisparityDerivativeModule() : SyncWrapperSystemModule("ImageDisparityDerivative") {
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY));
+    this->providesData.push_back(CARTSLAM_KEY_DISPARITY_DERIVATIVE);
+    this->providesData.push_back(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM);
+}
+
+static std::shared_ptr<EngineHandle> postEngine(std::mutex &mu, std::shared_ptr<EngineHandle> &slot, const image_t &disp) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!slot) {  // the post stages only need the geometry; SGM workspaces are sized for the smallest configuration
+        Size res; res.width = disp.cols; res.height = disp.rows;
+        cart_engine_params p = paramsFor(res, 0, 64, -1, 0, 4, 10, 120, 12);
+        slot = std::make_shared<EngineHandle>(res, p);
+    }
+    return slot;
+}
+
+system_data_t ImageDisparityDerivativeModule::runInternal(System &, SystemRunData &data) {
+    auto disparity = data.getData<image_t>(CARTSLAM_KEY_DISPARITY);
+    if (disparity->empty() || disparity->type() != CV_16SC1) throw std::runtime_error("Disparity must be of type CV_16SC1");
+    auto eng = postEngine(engineMutex, engine, *disparity);
+    auto derivatives = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_16SC2);
+    auto histogram = std::make_shared<image_t>(1, 256, CV_32SC2);
+    ScopedStream stream;
+    if (cart_disparity_derivative(eng->get(), 1, disparity->ptr<int16_t>(), disparity->step, 0, derivatives->ptr<int16_t>(), derivatives->step, 0,
+                                  histogram->ptr<int32_t>(), stream.s) != 0)
+        eng->fail("cart_disparity_derivative");
+    stream.wait();
+    return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_DISPARITY_DERIVATIVE), std::shared_ptr<void>(derivatives)),
+                             std::make_pair(std::string(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM), std::shared_ptr<void>(histogram)));
+}
+
+// ---------------------------------------------------------------- plane labels (planeseg.cu:246-458)
+DisparityPlaneSegmentationModule::DisparityPlaneSegmentationModule(std::shared_ptr<PlaneParameterProvider> provider, const int updateInterval, const int resetInterval,
+                                                                   const bool useTemporalSmoothing, const unsigned int, const bool labelComponents)
+    : SyncWrapperSystemModule("PlaneSegmentation"), updateInterval(updateInterval), resetInterval(resetInterval), labelComponents(labelComponents), planeParameterProvider(provider) {
+    if (useTemporalSmoothing)
+        throw std::runtime_error("use_temporal_smoothing needs the optical-flow module (NVIDIA fixed-function hardware in the reference): not supported");
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY));
+    this->providesData.push_back(CARTSLAM_KEY_PLANES);
+    if (labelComponents) this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENTS);
+}
+
+DisparityPlaneSegmentationModule::~DisparityPlaneSegmentationModule() {
+    if (derivativeHistogram) (void)hipFree(derivativeHistogram);
+}
+
+system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, SystemRunData &data) {
+    auto disparity = data.getData<image_t>(CARTSLAM_KEY_DISPARITY);
+    if (disparity->empty()) return MODULE_NO_RETURN_VALUE;  // planeseg.cu:250-253
+    if (disparity->type() != CV_16SC1) throw std::runtime_error("Disparity must be of type CV_16SC1");
+    auto eng = postEngine(engineMutex, engine, *disparity);
+    auto derivatives = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_16SC1);
+    {
+        std::shared_lock<std::shared_mutex> lock(derivativeHistogramMutex);  // read-lock section, planeseg.cu:269-288
+        {
+            static std::mutex createMutex;
+            std::lock_guard<std::mutex> lk(createMutex);
+            if (!derivativeHistogram) {
+                hipCheck(hipMalloc(reinterpret_cast<void **>(&derivativeHistogram), 256 * sizeof(int32_t)), "hipMalloc");
+                hipCheck(hipMemset(derivativeHistogram, 0, 256 * sizeof(int32_t)), "hipMemset");
+            }
+        }
+        ScopedStream stream;
+        if (cart_plane_derivative_hist(eng->get(), 1, disparity->ptr<int16_t>(), disparity->step, 0, derivatives->ptr<int16_t>(), derivatives->step, 0,
+                                       derivativeHistogram, 0, stream.s) != 0)
+            eng->fail("cart_plane_derivative_hist");
+        stream.wait();
+    }
+    this->updatePlaneParameters(system, data);
+
+    auto planes = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_8UC1);
+    const PlaneParameters pp = planeParameterProvider->getPlaneParameters();
+    cart_plane_params cp{pp.horizontalRange.first, pp.horizontalRange.second, pp.verticalRange.first, pp.verticalRange.second, pp.horizontalCenter, pp.verticalCenter};
+    ScopedStream stream;
+    if (cart_plane_classify(eng->get(), 1, derivatives->ptr<int16_t>(), derivatives->step, 0, &cp, 0, planes->ptr<uint8_t>(), planes->step, 0, stream.s) != 0)
+        eng->fail("cart_plane_classify");
+    std::shared_ptr<image_t> components;
+    if (labelComponents) {
+        components = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_32SC1);
+        if (cart_plane_ccl(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0, nullptr, stream.s) != 0)
+            eng->fail("cart_plane_ccl");
+    }
+    stream.wait();
+    if (labelComponents)
+        return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(planes)),
+                                 std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
+    return MODULE_RETURN(CARTSLAM_KEY_PLANES, planes);
+}
+
+void DisparityPlaneSegmentationModule::updatePlaneParameters(System &system, SystemRunData &data) {
+    if ((int)(data.id % (uint32_t)this->updateInterval) != 1) return;  // planeseg.cu:381-383
+    std::vector<int32_t> histogram(256);
+    {
+        std::unique_lock<std::shared_mutex> lock(derivativeHistogramMutex);
+        hipCheck(hipMemcpy(histogram.data(), derivativeHistogram, 256 * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy");
+        if ((int)(data.id % (uint32_t)(this->updateInterval * this->resetInterval)) == 1)
+            hipCheck(hipMemset(derivativeHistogram, 0, 256 * sizeof(int32_t)), "hipMemset");  // reset to avoid overflow (:391-394)
+    }
+    this->planeParameterProvider->updatePlaneParameters(system, data, histogram);
+    system.insertGlobalData(CARTSLAM_KEY_PLANE_PARAMETERS, std::make_shared<PlaneParameters>(this->planeParameterProvider->getPlaneParameters()));
+    system.insertGlobalData(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HIST, std::make_shared<std::vector<int32_t>>(histogram));
+}
+
+void HistogramPeakPlaneParameterProvider::updatePlaneParameters(System &, SystemRunData &, const std::vector<int32_t> &histogram) {
+    cart_plane_params p{horizontalRange.first, horizontalRange.second, verticalRange.first, verticalRange.second, horizontalCenter, verticalCenter};
+    if (cart_find_plane_params(histogram.data(), &p) < 0) throw std::runtime_error(std::string("cart_find_plane_params: ") + cart_last_error(nullptr));
+    horizontalRange = std::make_pair(p.horizontal_min, p.horizontal_max);
+    verticalRange = std::make_pair(p.vertical_min, p.vertical_max);
+    horizontalCenter = p.horizontal_center;
+    verticalCenter = p.vertical_center;
+}
+}  // namespace cart
