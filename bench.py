@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--disparities", type=int, default=128)
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,14 +93,18 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node; lets 2 ranks rehearse on 1 GPU
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
-                 max_inflight=B, device_id=local_rank)
+                 max_inflight=B, device_id=dev_index)
     pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True)
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     n_distinct = min(B, 4)
@@ -125,7 +130,7 @@ def main():
     stages, ncalls = eng.collect_timing()
     eng.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

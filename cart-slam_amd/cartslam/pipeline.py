@@ -86,8 +86,11 @@ class StereoPipeline:
             per_frame = [self.schedule.params] * n
         else:
             if self.world > 1:
-                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=left.device)
-                torch.distributed.all_gather_into_tensor(allh, self._hist, group=self.group)
+                # RCCL gathers device tensors; the gloo backend (CPU rehearsals) gathers host copies
+                on_host = torch.distributed.get_backend(self.group) == "gloo"
+                src = self._hist.cpu() if on_host else self._hist
+                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=src.device)
+                torch.distributed.all_gather_into_tensor(allh, src, group=self.group)
                 # [rank][k] -> id order k*world + rank
                 hists = allh.view(self.world, n, 256).permute(1, 0, 2).reshape(n * self.world, 256).cpu().numpy()
             else:
