@@ -67,9 +67,7 @@ struct cart_engine {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
-    int chunks = 1;                 // sub-batches per call (software pipeline over aux[0..1])
-    hipStream_t aux[2] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {};
+    int chunk_frames = 16;          // frames per launch sequence inside one batched call
     bool timing = false;
     std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
     size_t ring_calls = 0;
@@ -246,14 +244,6 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
             return fail("hipEventCreate failed");
         }
     build_agg_args(e);
-    if (const char *c = std::getenv("CART_CHUNKS")) e->chunks = std::max(1, std::atoi(c));
-    for (int s = 0; s < 2; ++s)
-        if (hipStreamCreateWithFlags(&e->aux[s], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_join[s], hipEventDisableTiming) != hipSuccess) {
-            cart_engine_destroy(e);
-            return fail("stream/event creation failed");
-        }
-    if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { cart_engine_destroy(e); return fail("hipEventCreate failed"); }
     *out = e;
     return 0;
 }
@@ -269,11 +259,6 @@ void cart_engine_destroy(cart_engine *e) {
     for (auto &r : e->ring)
         for (auto &ev : r.ev)
             if (ev) (void)hipEventDestroy(ev);
-    for (int s = 0; s < 2; ++s) {
-        if (e->aux[s]) (void)hipStreamDestroy(e->aux[s]);
-        if (e->ev_join[s]) (void)hipEventDestroy(e->ev_join[s]);
-    }
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 
@@ -404,25 +389,10 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
         }
         rec = rec_save;
     };
-    const int chunks = std::min(e->chunks, n_frames);
-    if (chunks <= 1) {
-        enqueue(0, n_frames, stream, true);
-    } else {
-        // software pipeline over sub-batches on two internal streams: the VALU-bound path aggregation of
-        // one chunk overlaps the HBM-bound winner-takes-all of the previous one
-        (void)hipEventRecord(e->ev_fork, stream);
-        for (int s = 0; s < 2; ++s) (void)hipStreamWaitEvent(e->aux[s], e->ev_fork, 0);
-        int f0 = 0;
-        for (int c = 0; c < chunks; ++c) {
-            const int n = (n_frames - f0) / (chunks - c);
-            enqueue(f0, n, e->aux[c & 1], c == 0);
-            f0 += n;
-        }
-        for (int s = 0; s < 2; ++s) {
-            (void)hipEventRecord(e->ev_join[s], e->aux[s]);
-            (void)hipStreamWaitEvent(stream, e->ev_join[s], 0);
-        }
-    }
+    // Large batches run as cache-sized sub-batches on the caller's stream: the census planes every direction
+    // re-reads (4.2 MB per frame) then stay in L2 + Infinity Cache (measured: 64 frames in one launch are 13 %
+    // slower per frame than 4 x 16).  Two-stream overlap of sub-batches was measured and buys nothing.
+    for (int f0 = 0; f0 < n_frames; f0 += e->chunk_frames) enqueue(f0, std::min(e->chunk_frames, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
     release(l);
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));

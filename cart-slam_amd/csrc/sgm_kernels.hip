@@ -3,9 +3,9 @@
 // Replaces what cv::cuda::StereoSGM::compute does for the reference
 // (src/modules/disparity/disparity.cu:71): census 9x7, per-direction path
 // aggregation into u8 cost slabs, winner-takes-all with uniqueness / sub-pixel / right view,
-// 3x3 medians, left-right check and range fix.  Written for wave64: one scan line is owned by
-// one 16-lane DPP row (D/16 disparities per lane), neighbour exchange and the min over D are
-// DPP row_shr/row_shl/row_ror ops, no LDS and no barriers in the recurrence.
+// 3x3 medians, left-right check and range fix.  Written for wave64: a pixel is owned by D/16
+// adjacent lanes (16 disparities per lane, packed u16 pairs), neighbour exchange and the min over
+// D are DPP ops inside a 16-lane row; see the comments at each kernel.
 #include "engine_internal.h"
 
 namespace cart_amd {
@@ -13,24 +13,8 @@ namespace cart_amd {
 // ------------------------------------------------------------------ DPP helpers
 constexpr int DPP_ROW_SHL1 = 0x101;
 constexpr int DPP_ROW_SHR1 = 0x111;
-constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
-
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_keep(uint32_t old, uint32_t v) {
-    // lanes without a valid source inside their 16-lane row keep `old`
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ uint32_t row_allmin(uint32_t v) {
-    v = min(v, dpp_keep<DPP_ROW_ROR8>(v, v));
-    v = min(v, dpp_keep<DPP_ROW_ROR4>(v, v));
-    v = min(v, dpp_keep<DPP_ROW_ROR2>(v, v));
-    v = min(v, dpp_keep<DPP_ROW_ROR1>(v, v));
-    return v;
-}
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 template <int N>
 __device__ __forceinline__ void load_u32s(const uint32_t *p, uint32_t (&r)[N]) {
@@ -39,47 +23,6 @@ __device__ __forceinline__ void load_u32s(const uint32_t *p, uint32_t (&r)[N]) {
     for (int i = 0; i < N / 4; ++i) {
         u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p + 4 * i);
         r[4 * i + 0] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
-    }
-}
-
-__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    return a | (b << 8) | (c << 16) | (d << 24);
-}
-
-template <int N>
-__device__ __forceinline__ void store_u8s(uint8_t *p, const uint32_t (&v)[N]) {
-    if constexpr (N == 4) {
-        *reinterpret_cast<uint32_t *>(p) = pack4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (N == 8) {
-        uint2 o = make_uint2(pack4(v[0], v[1], v[2], v[3]), pack4(v[4], v[5], v[6], v[7]));
-        *reinterpret_cast<uint2 *>(p) = o;
-    } else {
-        uint4 o = make_uint4(pack4(v[0], v[1], v[2], v[3]), pack4(v[4], v[5], v[6], v[7]),
-                             pack4(v[8], v[9], v[10], v[11]), pack4(v[12], v[13], v[14], v[15]));
-        *reinterpret_cast<uint4 *>(p) = o;
-    }
-}
-
-// slab bytes are read exactly once (by the WTA): non-temporal loads keep them from displacing reusable lines
-template <int N>
-__device__ __forceinline__ void load_u8s_add(const uint8_t *p, uint32_t (&acc)[N]) {
-    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    if constexpr (N == 4) {
-        uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += (v >> (8 * i)) & 0xffu;
-    } else if constexpr (N == 8) {
-        v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i] += (v.x >> (8 * i)) & 0xffu; acc[4 + i] += (v.y >> (8 * i)) & 0xffu; }
-    } else {
-        v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += (v.x >> (8 * i)) & 0xffu; acc[4 + i] += (v.y >> (8 * i)) & 0xffu;
-            acc[8 + i] += (v.z >> (8 * i)) & 0xffu; acc[12 + i] += (v.w >> (8 * i)) & 0xffu;
-        }
     }
 }
 
