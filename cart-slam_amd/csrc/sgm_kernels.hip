@@ -27,22 +27,26 @@ __device__ __forceinline__ void load_u32s(const uint32_t *p, uint32_t (&r)[N]) {
 }
 
 // ------------------------------------------------------------------ gray + census
-// One block = 64x16 output pixels of one image; LDS tile with a 4-column / 3-row halo.
-// BGR->gray (oracle S1) is fused into the tile load; the gray plane is written out because the
-// left-right check masks on gray_left == 0.  Also resets the packed right-view minima.
-constexpr int CT_W = 64, CT_H = 16, CT_LW = CT_W + 8, CT_LH = CT_H + 6;
+// One block = 64x16 output pixels of one image; LDS tile with a 4-column / 3-row halo.  BGR->gray (oracle S1)
+// is fused into the tile load; the gray plane is written out because the left-right check masks on
+// gray_left == 0.  Each thread produces 4 horizontally adjacent features from 7 x 3 aligned dword reads of the
+// tile (its 12-byte-wide window), so the 31 comparisons per pixel run on register bytes.  The kernel also
+// resets the packed right-view minima.
+constexpr int CT_W = 64, CT_H = 16, CT_LW = CT_W + 8, CT_LH = CT_H + 6, CT_PITCH = 76;  // bytes; 19 dwords per row
+
+__device__ __forceinline__ uint32_t win_byte(const uint32_t (&w)[3], int c) { return (w[c >> 2] >> (8 * (c & 3))) & 0xffu; }
 
 __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch right, int channels,
                                                      uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l,
                                                      uint32_t *cen_r, uint32_t *right_pk, Geometry g) {
-    __shared__ uint8_t tile[CT_LH][CT_LW + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[CT_LH * CT_PITCH];
     const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
     const ImageBatch img = side ? right : left;
     const uint8_t *src = img.ptr + (size_t)frame * img.frame_stride;
     uint8_t *gray = (side ? gray_r : gray_l) + (size_t)frame * g.npx;
     uint32_t *cen = (side ? cen_r : cen_l) + (size_t)frame * g.census_elems;
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int tid = threadIdx.x;
 
     for (int i = tid; i < CT_LH * CT_LW; i += 256) {
         const int ty = i / CT_LW, tx = i - ty * CT_LW;
@@ -58,27 +62,39 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
             }
             if (tx >= 4 && tx < 4 + CT_W && ty >= 3 && ty < 3 + CT_H) gray[(size_t)gy * g.w + gx] = (uint8_t)v;
         }
-        tile[ty][tx] = (uint8_t)v;
+        tile[ty * CT_PITCH + tx] = (uint8_t)v;
     }
     __syncthreads();
 
-    const int x = x0 + threadIdx.x;
+    // thread -> 4 pixels: tile columns 4*tq+4 .. 4*tq+7 of row ly (window = tile columns 4*tq .. 4*tq+11)
+    const int tq = tid & 15, ly = tid >> 4;
+    const int y = y0 + ly, xb = x0 + 4 * tq;
+    if (y >= g.h || xb >= g.w) return;
+    uint32_t w[7][3];
 #pragma unroll
-    for (int r = 0; r < CT_H / 4; ++r) {
-        const int ly = threadIdx.y + 4 * r, y = y0 + ly;
-        if (x >= g.w || y >= g.h) continue;
-        uint32_t f = 0;
-        if (x >= 4 && x < g.w - 4 && y >= 3 && y < g.h - 3) {
-            const int cx = threadIdx.x + 4, cy = ly + 3;
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * CT_PITCH) + tq;
+        w[r][0] = rp[0]; w[r][1] = rp[1]; w[r][2] = rp[2];
+    }
+    uint32_t f[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int dy = -3; dy < 0; ++dy)
+    for (int dy = -3; dy < 0; ++dy)
 #pragma unroll
-                for (int dx = -4; dx <= 4; ++dx)
-                    f = (f << 1) | (uint32_t)(tile[cy + dy][cx + dx] > tile[cy - dy][cx - dx]);
+        for (int dx = -4; dx <= 4; ++dx)
 #pragma unroll
-            for (int dx = -4; dx < 0; ++dx) f = (f << 1) | (uint32_t)(tile[cy][cx + dx] > tile[cy][cx - dx]);
-        }
-        cen[(size_t)y * g.cpitch + g.cpadl + x] = f;
+            for (int i = 0; i < 4; ++i)
+                f[i] = (f[i] << 1) | (uint32_t)(win_byte(w[3 + dy], 4 + i + dx) > win_byte(w[3 - dy], 4 + i - dx));
+#pragma unroll
+    for (int dx = -4; dx < 0; ++dx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (f[i] << 1) | (uint32_t)(win_byte(w[3], 4 + i + dx) > win_byte(w[3], 4 + i - dx));
+    const bool yin = y >= 3 && y < g.h - 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = xb + i;
+        if (x >= g.w) break;
+        const bool inner = yin && x >= 4 && x < g.w - 4;  // oracle S2: border features are 0
+        cen[(size_t)y * g.cpitch + g.cpadl + x] = inner ? f[i] : 0u;
         if (side == 0) right_pk[(size_t)frame * g.npx + (size_t)y * g.w + x] = 0xffffffffu;
     }
 }
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
 void launch_census(const ImageBatch &left, const ImageBatch &right, int channels, int n_frames, uint8_t *gray_l,
                    uint8_t *gray_r, uint32_t *cen_l, uint32_t *cen_r, uint32_t *right_pk, const Geometry &g,
                    hipStream_t s) {
-    dim3 grid((g.w + CT_W - 1) / CT_W, (g.h + CT_H - 1) / CT_H, n_frames * 2), block(64, 4);
+    dim3 grid((g.w + CT_W - 1) / CT_W, (g.h + CT_H - 1) / CT_H, n_frames * 2), block(256);
     hipLaunchKernelGGL(census_kernel, grid, block, 0, s, left, right, channels, gray_l, gray_r, cen_l, cen_r,
                        right_pk, g);
 }
