@@ -41,6 +41,11 @@ PROTOTYPES = {
     "cart_plane_derivative_hist": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
     "cart_plane_classify": (_i, [_vp, _i, _vp, _sz, _sz, C.POINTER(PlaneParams), _i, _vp, _sz, _sz, _vp]),
     "cart_plane_ccl": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
+    "cart_plane_schedule_create": (_i, [_vp, _i, C.POINTER(PlaneParams), _i, _i, C.POINTER(_vp)]),
+    "cart_plane_schedule_destroy": (None, [_vp]),
+    "cart_plane_schedule_advance": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "cart_plane_schedule_read": (_i, [_vp, C.POINTER(PlaneParams), C.POINTER(C.c_int32)]),
+    "cart_plane_classify_dev": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _i, _vp, _sz, _sz, _vp]),
     "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),

@@ -140,6 +140,21 @@ class Engine:
                                                   _stream_ptr()), "cart_plane_classify")
         return planes
 
+    def plane_classify_dev(self, deriv, params_dev):
+        """params_dev: int32 CUDA tensor [n,6] (one cart_plane_params per frame) or [6] (shared)."""
+        import torch
+        n, p, s, fs = _geom(deriv, 1)
+        if params_dev.dtype != torch.int32 or not params_dev.is_contiguous() or not params_dev.is_cuda:
+            raise EngineError("params_dev must be a contiguous int32 CUDA tensor")
+        per_frame = params_dev.dim() == 2
+        if per_frame and params_dev.shape[0] != n:
+            raise EngineError("one parameter row per frame expected")
+        planes = torch.empty(deriv.shape, dtype=torch.uint8, device=deriv.device)
+        _, pp, ps, pfs = _geom(planes, 1)
+        self._check(self._lib.cart_plane_classify_dev(self._h, n, p, s, fs, C.c_void_p(params_dev.data_ptr()), 1 if per_frame else 0,
+                                                      pp, ps, pfs, _stream_ptr()), "cart_plane_classify_dev")
+        return planes
+
     def plane_ccl(self, planes):
         import torch
         n, p, s, fs = _geom(planes, 1)
@@ -181,6 +196,52 @@ class Engine:
         if n < 0:
             raise EngineError("cart_engine_collect_timing: " + self._lib.cart_last_error(self._h).decode())
         return {names[i].decode(): float(ms[i]) for i in range(n)}, calls.value
+
+
+class DevicePlaneSchedule:
+    """Device-side replay of the reference's plane-parameter bookkeeping (cart_plane_schedule_* in the C ABI)."""
+
+    def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10):
+        if provider not in ("histogram_peak", "static"):
+            raise ValueError("Unknown parameter provider type.")  # cartconfig.cpp:77
+        self._eng = engine
+        self._lib = engine._lib
+        init = PlaneParams(*(static_params or (0,) * 6))
+        self._h = C.c_void_p()
+        rc = self._lib.cart_plane_schedule_create(engine._h, 1 if provider == "histogram_peak" else 0, C.byref(init), update_interval,
+                                                  reset_interval, C.byref(self._h))
+        if rc != 0:
+            raise EngineError("cart_plane_schedule_create: " + self._lib.cart_last_error(engine._h).decode())
+
+    def advance(self, first_id, hists):
+        """hists: int32 CUDA [n,256] in frame-id order -> int32 CUDA [n,6] parameters per frame."""
+        import torch
+        if hists.dtype != torch.int32 or not hists.is_contiguous() or hists.dim() != 2 or hists.shape[1] != 256:
+            raise EngineError("hists must be a contiguous int32 [n,256] CUDA tensor")
+        out = torch.empty((hists.shape[0], 6), dtype=torch.int32, device=hists.device)
+        rc = self._lib.cart_plane_schedule_advance(self._h, first_id, hists.shape[0], C.c_void_p(hists.data_ptr()),
+                                                   C.c_void_p(out.data_ptr()), _stream_ptr())
+        if rc != 0:
+            raise EngineError("cart_plane_schedule_advance: " + self._lib.cart_last_error(self._eng._h).decode())
+        return out
+
+    def read(self):
+        p = PlaneParams()
+        cum = (C.c_int32 * 256)()
+        if self._lib.cart_plane_schedule_read(self._h, C.byref(p), cum) != 0:
+            raise EngineError("cart_plane_schedule_read: " + self._lib.cart_last_error(self._eng._h).decode())
+        return p, np.array(cum, dtype=np.int32)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cart_plane_schedule_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def find_plane_params(hist256, params=None):

@@ -56,11 +56,17 @@ def shard_ids(first_id, n_local, rank, world):
 
 
 class StereoPipeline:
+    """device_schedule=True (default) replays the plane-parameter bookkeeping on the GPU
+    (cart_plane_schedule_advance), so a step has no device->host round trip; False uses the host restatement
+    (PlaneParameterSchedule + cart_find_plane_params), which is what the reference's module does per frame."""
+
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
-                 with_ccl=True, group=None):
+                 with_ccl=True, group=None, device_schedule=True):
         import torch
+        from .engine import DevicePlaneSchedule
         self.engine = engine
         self.schedule = PlaneParameterSchedule(provider, static_params, update_interval, reset_interval)
+        self.dev_schedule = DevicePlaneSchedule(engine, provider, static_params, update_interval, reset_interval) if device_schedule else None
         self.with_ccl = with_ccl
         self.group = group
         self.world = 1
@@ -82,6 +88,24 @@ class StereoPipeline:
             self._hist = torch.empty((n, 256), dtype=torch.int32, device=left.device)
         self._hist.zero_()
         deriv = eng.plane_derivative_hist(disp, self._hist, per_frame_hist=True)
+        if self.dev_schedule is not None:
+            hists = self._hist
+            if self.world > 1 and self.schedule.provider != "static":
+                on_host = torch.distributed.get_backend(self.group) == "gloo"
+                src = self._hist.cpu() if on_host else self._hist
+                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=src.device)
+                torch.distributed.all_gather_into_tensor(allh, src, group=self.group)
+                hists = allh.view(self.world, n, 256).permute(1, 0, 2).reshape(n * self.world, 256).contiguous().to(left.device)
+            if self.world > 1 and self.schedule.provider == "static":
+                hists = self._hist.new_zeros((n * self.world, 256))
+            allp = self.dev_schedule.advance(self.next_id, hists)
+            mine = allp[self.rank::self.world].contiguous() if self.world > 1 else allp
+            self.next_id += n * self.world
+            planes = eng.plane_classify_dev(deriv, mine)
+            out = dict(disparity=disp, planes=planes, params=mine)
+            if self.with_ccl:
+                out["ids"], out["n_components"] = eng.plane_ccl(planes)
+            return out
         if self.schedule.provider == "static":
             per_frame = [self.schedule.params] * n
         else:

@@ -508,6 +508,75 @@ int cart_plane_ccl(cart_engine *e, int n_frames, const uint8_t *planes, size_t p
     return 0;
 }
 
+struct cart_plane_schedule {
+    cart_engine *engine;
+    ScheduleState *state;  // device
+    int provider, update_interval, reset_interval;
+};
+
+int cart_plane_schedule_create(cart_engine *e, int provider, const cart_plane_params *initial, int update_interval,
+                               int reset_interval, cart_plane_schedule **out) {
+    if (!e || !out) return fail("bad arguments");
+    if (provider != 0 && provider != 1) return fail("Unknown parameter provider type.");
+    if (update_interval < 1 || reset_interval < 1) return fail("intervals must be >= 1");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    cart_plane_schedule *s = new (std::nothrow) cart_plane_schedule{e, nullptr, provider, update_interval, reset_interval};
+    if (!s) return fail("out of host memory");
+    ScheduleState init;
+    std::memset(&init, 0, sizeof(init));
+    if (initial) init.params = *initial;
+    if (hipMalloc(reinterpret_cast<void **>(&s->state), sizeof(ScheduleState)) != hipSuccess ||
+        hipMemcpy(s->state, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+        cart_plane_schedule_destroy(s);
+        return fail("hipMalloc/hipMemcpy of the schedule state failed");
+    }
+    *out = s;
+    return 0;
+}
+
+void cart_plane_schedule_destroy(cart_plane_schedule *s) {
+    if (!s) return;
+    if (s->state) (void)hipFree(s->state);
+    delete s;
+}
+
+int cart_plane_schedule_advance(cart_plane_schedule *s, int first_id, int n_frames, const int32_t *hists,
+                                cart_plane_params *params_out, void *stream) {
+    if (!s || !hists || !params_out) return fail("bad arguments");
+    if (n_frames <= 0 || first_id < 1) return fail("n_frames must be positive and ids are 1-based");
+    HIP_TRY(hipSetDevice(s->engine->params.device_id));
+    launch_plane_schedule(s->state, s->provider, first_id, n_frames, s->update_interval, s->reset_interval, hists, params_out,
+                          static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_plane_schedule_read(cart_plane_schedule *s, cart_plane_params *params_host, int32_t cum_hist_host[256]) {
+    if (!s) return fail("bad arguments");
+    HIP_TRY(hipSetDevice(s->engine->params.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    ScheduleState st;
+    HIP_TRY(hipMemcpy(&st, s->state, sizeof(st), hipMemcpyDeviceToHost));
+    if (params_host) *params_host = st.params;
+    if (cum_hist_host) std::memcpy(cum_hist_host, st.cum, sizeof(st.cum));
+    return 0;
+}
+
+int cart_plane_classify_dev(cart_engine *e, int n_frames, const int16_t *deriv, size_t deriv_step, size_t deriv_frame_stride,
+                            const cart_plane_params *params_dev, int params_stride, uint8_t *planes, size_t planes_step,
+                            size_t planes_frame_stride, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!deriv || !planes || !params_dev) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (deriv_step < (size_t)g.w * 2 || planes_step < (size_t)g.w || (deriv_step & 1) || (deriv_frame_stride & 1)) return fail("bad step");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    launch_classify_dev(deriv, deriv_step, deriv_frame_stride, params_dev, params_stride ? 1 : 0, planes, planes_step, planes_frame_stride,
+                        g.w, g.h, n_frames, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- host-side peak finder (replaces src/utils/peaks.cpp:12-72 and planeseg.cu:405-458) ----
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right) {
     if (!data || n <= 0 || !born || !died || !left || !right) return fail("bad arguments");

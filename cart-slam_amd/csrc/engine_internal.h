@@ -74,6 +74,15 @@ void launch_classify(const int16_t *deriv, size_t step, size_t fs, const Classif
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
                 int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
 
+void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params_dev, int params_stride,
+                         uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s);
+struct ScheduleState {   // device resident
+    int32_t cum[256];
+    cart_plane_params params;
+};
+void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int n_frames, int update_interval, int reset_interval,
+                           const int32_t *hists, cart_plane_params *params_out, hipStream_t s);
+
 int kernel_count();
 
 }  // namespace cart_amd

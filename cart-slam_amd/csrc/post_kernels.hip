@@ -168,6 +168,112 @@ void launch_classify(const int16_t *deriv, size_t step, size_t fs, const Classif
     hipLaunchKernelGGL(classify_kernel, grid, block, 0, s, deriv, step, fs, params, per_frame, planes, pstep, pfs, w, h);
 }
 
+__global__ __launch_bounds__(256) void classify_dev_kernel(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params,
+                                                           int params_stride, uint8_t *planes, size_t pstep, size_t pfs, int w, int h) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const cart_plane_params pp = params[(size_t)frame * params_stride];
+    const int d = row_ptr(deriv, fs, step, frame, y)[x];
+    int plane = CART_PLANE_UNKNOWN;
+    if (d != INVALID && d >= pp.horizontal_min && d < pp.horizontal_max) plane = CART_PLANE_HORIZONTAL;
+    else if (d != INVALID && d >= pp.vertical_min && d < pp.vertical_max) plane = CART_PLANE_VERTICAL;
+    row_ptr(planes, pfs, pstep, frame, y)[x] = (uint8_t)plane;
+}
+
+void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params_dev, int params_stride,
+                         uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    hipLaunchKernelGGL(classify_dev_kernel, grid, block, 0, s, deriv, step, fs, params_dev, params_stride, planes, pstep, pfs, w, h);
+}
+
+// ------------------------------------------------------------------ plane-parameter schedule (device replay)
+// One block replays the frames of a batch in id order (planeseg.cu:379-403).  At a refresh frame the 256 bins are
+// ranked in parallel (descending value, ties by ascending index: oracle S11), then thread 0 runs the persistence
+// scan of util::findPeaks (peaks.cpp:32-67), picks the two most persistent peaks (stable order) and derives the
+// ranges exactly like HistogramPeakPlaneParameterProvider::updatePlaneParameters (planeseg.cu:408-453).
+__global__ __launch_bounds__(256) void plane_schedule_kernel(ScheduleState *state, int provider, int first_id, int n_frames,
+                                                             int update_interval, int reset_interval, const int32_t *hists,
+                                                             cart_plane_params *params_out) {
+    __shared__ int32_t cum[256], hsnap[256];
+    __shared__ int order[256], owner[256];
+    __shared__ int born[130], died[130], lft[130], rgt[130];
+    __shared__ cart_plane_params cur;
+    const int t = threadIdx.x;
+    cum[t] = state->cum[t];
+    if (t == 0) cur = state->params;
+    __syncthreads();
+    for (int k = 0; k < n_frames; ++k) {
+        const int fid = first_id + k;
+        cum[t] += hists[(size_t)k * 256 + t];
+        const bool refresh = fid % update_interval == 1;                          // planeseg.cu:381
+        if (refresh) {
+            hsnap[t] = cum[t];                                                    // "download" (:389)
+            if (fid % (update_interval * reset_interval) == 1) cum[t] = 0;        // reset after download (:391-394)
+        }
+        __syncthreads();
+        if (refresh && provider == 1) {
+            const int v = hsnap[t];
+            int rank = 0;
+            for (int j = 0; j < 256; ++j) {
+                const int u = hsnap[j];
+                rank += (u > v) || (u == v && j < t);
+            }
+            order[rank] = t;
+            owner[t] = -1;
+            __syncthreads();
+            if (t == 0) {
+                int np = 0;
+                for (int o = 0; o < 256; ++o) {
+                    const int idx = order[o];
+                    const int il = idx > 0 ? owner[idx - 1] : -1, ir = idx < 255 ? owner[idx + 1] : -1;
+                    if (il < 0 && ir < 0) { born[np] = lft[np] = rgt[np] = idx; died[np] = -1; owner[idx] = np++; }
+                    else if (il >= 0 && ir < 0) { rgt[il] += 1; owner[idx] = il; }
+                    else if (il < 0 && ir >= 0) { lft[ir] -= 1; owner[idx] = ir; }
+                    else if (hsnap[born[il]] > hsnap[born[ir]]) { died[ir] = idx; rgt[il] = rgt[ir]; owner[rgt[il]] = owner[idx] = il; }
+                    else { died[il] = idx; lft[ir] = lft[il]; owner[lft[ir]] = owner[idx] = ir; }
+                }
+                if (np >= 2) {
+                    // two most persistent peaks, first-born wins ties (stable sort of peaks.cpp:70)
+                    int b0 = -1, b1 = -1;
+                    long long p0 = -1, p1 = -1;
+                    for (int i = 0; i < np; ++i) {
+                        const long long pers = died[i] < 0 ? 2147483647LL : (long long)hsnap[born[i]] - hsnap[died[i]];
+                        if (pers > p0) { b1 = b0; p1 = p0; b0 = i; p0 = pers; }
+                        else if (pers > p1) { b1 = i; p1 = pers; }
+                    }
+                    int pv = born[b0], ph = born[b1];
+                    if (abs(pv - 128) > abs(ph - 128)) { const int tmp = pv; pv = ph; ph = tmp; }
+                    cur.vertical_center = pv - 128;
+                    cur.horizontal_center = ph - 128;
+                    int valley = min(pv, ph);
+                    for (int i = valley; i < max(pv, ph); ++i)
+                        if (hsnap[i] < hsnap[valley]) valley = i;
+                    const int vdist = abs(valley - pv), hdist = abs(valley - ph);
+                    if (vdist != 0 && hdist != 0) {
+                        const int vslope = (hsnap[pv] - hsnap[valley]) / vdist, hslope = (hsnap[ph] - hsnap[valley]) / hdist;
+                        if (vslope != 0 && hslope != 0) {
+                            const int vwidth = hsnap[pv] / vslope, hwidth = hsnap[ph] / hslope;
+                            cur.vertical_min = pv - vwidth - 128; cur.vertical_max = valley - 127;
+                            cur.horizontal_min = valley - 127; cur.horizontal_max = ph + hwidth - 127;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (t == 0) params_out[k] = cur;
+        __syncthreads();
+    }
+    state->cum[t] = cum[t];
+    if (t == 0) state->params = cur;
+}
+
+void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int n_frames, int update_interval, int reset_interval,
+                           const int32_t *hists, cart_plane_params *params_out, hipStream_t s) {
+    hipLaunchKernelGGL(plane_schedule_kernel, dim3(1), dim3(256), 0, s, state, provider, first_id, n_frames, update_interval, reset_interval,
+                       hists, params_out);
+}
+
 // ------------------------------------------------------------------ connected components (run-based union-find)
 // 1. ccl_runs:    every pixel links to the first pixel of its horizontal run (block scan per row),
 // 2. ccl_merge:   one union per pair of vertically touching runs (only where a run starts above or
@@ -238,13 +344,16 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t *planes, s
     ccl_union(L, L[y * w + x], L[(y - 1) * w + x]);
 }
 
-__global__ __launch_bounds__(256) void ccl_compress_kernel(int32_t *work, int32_t *ncomp, int w, int h, size_t npx) {
+__global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
+                                                           int32_t *ncomp, int w, int h, size_t npx) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= w || y >= h) return;
+    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
+    const uint8_t c = row[x];
+    if (c > 1 || (x > 0 && row[x - 1] == c)) return;  // only run heads carry links that others follow
     int32_t *L = work + (size_t)frame * npx;
     const int i = y * w + x;
     const int p = L[i];
-    if (p < 0) return;
     if (p == i) {  // a root: nothing links it further, nobody rewrites it in this pass
         if (ncomp) atomicAdd(&ncomp[frame], 1);
         return;
@@ -265,7 +374,7 @@ __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int
     int r = L[y * w + x];
     if (r >= 0) {
         int q = L[r];
-        while (q != r) { r = q; q = L[r]; }  // at most a couple of hops after ccl_compress
+        while (q != r) { r = q; q = L[r]; }  // pixel -> run head -> root after ccl_compress
     }
     row_ptr(ids, ifs, istep, frame, y)[x] = r;
 }
@@ -280,10 +389,10 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
         dim3 mgrid((w + 63) / 64, (h - 1 + 3) / 4, n_frames);
         hipLaunchKernelGGL(ccl_merge_kernel, mgrid, block, 0, s, planes, pstep, pfs, work, w, h, npx);
     }
-    hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, work, ncomp, w, h, npx);
+    hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, planes, pstep, pfs, work, ncomp, w, h, npx);
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 13; }
+int kernel_count() { return 16; }
 
 }  // namespace cart_amd

@@ -126,6 +126,30 @@ int cart_plane_ccl(cart_engine *engine, int n_frames,
  * *inout was updated, 0 on the reference's early-outs (parameters kept), <0 on error. */
 int cart_find_plane_params(const int32_t hist256[256], cart_plane_params *inout);
 
+/* Device-side plane-parameter schedule for the batched-frame mode: the same bookkeeping as
+ * DisparityPlaneSegmentationModule::updatePlaneParameters (planeseg.cu:379-403: cumulative histogram, refresh when
+ * id % update_interval == 1, reset when id % (update_interval*reset_interval) == 1) + the histogram_peak provider
+ * (planeseg.cu:405-458) + util::findPeaks (peaks.cpp:12-72), replayed in frame-id order by one small kernel so
+ * that a batch needs no device->host round trip.  `hists` = per-frame histograms [n_frames][256] (device, e.g. from
+ * cart_plane_derivative_hist with hist_frame_stride_elems = 256, all-gathered across ranks in id order);
+ * `params_out` = [n_frames] cart_plane_params (device) the frames are to be classified with.
+ * provider: 0 = static (params_out = initial for every frame), 1 = histogram_peak. */
+typedef struct cart_plane_schedule cart_plane_schedule;
+int cart_plane_schedule_create(cart_engine *engine, int provider, const cart_plane_params *initial, int update_interval,
+                               int reset_interval, cart_plane_schedule **out);
+void cart_plane_schedule_destroy(cart_plane_schedule *schedule);
+int cart_plane_schedule_advance(cart_plane_schedule *schedule, int first_id, int n_frames, const int32_t *hists,
+                                cart_plane_params *params_out, void *stream);
+/* Synchronises and copies the schedule's current parameters / cumulative histogram to the host (tests). */
+int cart_plane_schedule_read(cart_plane_schedule *schedule, cart_plane_params *params_host, int32_t cum_hist_host[256]);
+
+/* cart_plane_classify with the per-frame parameters in DEVICE memory (output of cart_plane_schedule_advance);
+ * params_stride = 1 -> params[frame], 0 -> params[0] for every frame. */
+int cart_plane_classify_dev(cart_engine *engine, int n_frames,
+                            const int16_t *deriv, size_t deriv_step, size_t deriv_frame_stride,
+                            const cart_plane_params *params_dev, int params_stride,
+                            uint8_t *planes, size_t planes_step, size_t planes_frame_stride, void *stream);
+
 /* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
 

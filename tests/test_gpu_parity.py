@@ -301,8 +301,16 @@ def test_batched_pipeline_matches_frame_by_frame_oracle(torch_cuda):
     w, h, D, P, n = 256, 96, 64, 8, 7
     ui, ri = 3, 2
     eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=4)
-    pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True)
     ls, rs = synth.make_batch(n, w, h, D, 4, seed=99)
+    for device_schedule in (True, False):
+        _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule)
+    eng.close()
+
+
+def _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule):
+    from cartslam.pipeline import StereoPipeline
+    pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True,
+                          device_schedule=device_schedule)
     outs = []
     for a in range(0, n, 4):  # batches of 4, then 3
         o = pipe.process_batch(dev(torch, ls[a:a + 4]), dev(torch, rs[a:a + 4]))
@@ -326,4 +334,31 @@ def test_batched_pipeline_matches_frame_by_frame_oracle(torch_cuda):
         assert (planes[f] == ep).all(), f"planes frame {fid}"
         eids, en = O.ccl(ep)
         assert (ids[f] == eids).all() and ncomp[f] == en, f"ccl frame {fid}"
+
+
+def test_device_plane_schedule_matches_host_restatement(torch_cuda):
+    """cart_plane_schedule_advance (one small kernel, no host round trip) against the host restatement that is itself
+    checked against the sequential reference order in tests/test_distributed.py."""
+    torch = torch_cuda
+    from cartslam import DevicePlaneSchedule
+    from cartslam.pipeline import PlaneParameterSchedule
+    from test_distributed import make_hists
+    eng = make_engine(64, 32, 64, 4)
+    rng = np.random.default_rng(17)
+    extra = [rng.integers(0, 40, 256), rng.integers(0, 5, 256) * rng.integers(0, 3000, 256), np.zeros(256), np.full(256, 7)]
+    hists = np.concatenate([make_hists(70), np.stack(extra).astype(np.int32)])
+    for ui, ri in ((30, 10), (7, 2), (3, 3)):
+        host = PlaneParameterSchedule("histogram_peak", update_interval=ui, reset_interval=ri)
+        devs = DevicePlaneSchedule(eng, "histogram_peak", None, ui, ri)
+        a = 0
+        for n in (16, 5, 1, 30, 22):
+            exp = [p.as_tuple() for p in host.advance(a + 1, hists[a:a + n])]
+            got = devs.advance(a + 1, dev(torch, hists[a:a + n])).cpu().numpy()
+            assert [tuple(int(v) for v in row) for row in got] == exp, (ui, ri, a)
+            a += n
+        p, cum = devs.read()
+        assert p.as_tuple() == host.params.as_tuple() and (cum == host.cum.astype(np.int32)).all()
+        devs.close()
+    st = DevicePlaneSchedule(eng, "static", (6, 18, -5, 6, 12, 0))
+    assert (st.advance(1, dev(torch, hists[:3])).cpu().numpy() == np.array([(6, 18, -5, 6, 12, 0)] * 3)).all()
     eng.close()
