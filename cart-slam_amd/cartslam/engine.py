@@ -155,6 +155,16 @@ class Engine:
                                                       pp, ps, pfs, _stream_ptr()), "cart_plane_classify_dev")
         return planes
 
+    # ---- depth module (reference src/modules/depth.cpp:9-25) ----
+    def reproject_depth(self, disp, Q):
+        import torch
+        n, p, s, fs = _geom(disp, 1)
+        q = (C.c_float * 16)(*[float(v) for v in np.asarray(Q, np.float32).reshape(16)])
+        out = torch.empty(tuple(disp.shape) + (3,), dtype=torch.float32, device=disp.device)
+        _, op, os_, ofs = _geom(out, 2)
+        self._check(self._lib.cart_reproject_depth(self._h, n, p, s, fs, q, op, os_, ofs, _stream_ptr()), "cart_reproject_depth")
+        return out
+
     def plane_ccl(self, planes):
         import torch
         n, p, s, fs = _geom(planes, 1)

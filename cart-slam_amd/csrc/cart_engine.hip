@@ -577,6 +577,22 @@ int cart_plane_classify_dev(cart_engine *e, int n_frames, const int16_t *deriv, 
     return 0;
 }
 
+int cart_reproject_depth(cart_engine *e, int n_frames, const int16_t *disp, size_t disp_step, size_t disp_frame_stride, const float Q[16],
+                         float *xyz, size_t xyz_step, size_t xyz_frame_stride, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!disp || !xyz || !Q) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (disp_step < (size_t)g.w * 2 || (disp_step & 1) || (disp_frame_stride & 1) || xyz_step < (size_t)g.w * 12 || (xyz_step & 3) || (xyz_frame_stride & 3))
+        return fail("bad step");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    QMatrix q;
+    std::memcpy(q.q, Q, sizeof(q.q));
+    launch_reproject(disp, disp_step, disp_frame_stride, q, xyz, xyz_step, xyz_frame_stride, g.w, g.h, n_frames, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- host-side peak finder (replaces src/utils/peaks.cpp:12-72 and planeseg.cu:405-458) ----
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right) {
     if (!data || n <= 0 || !born || !died || !left || !right) return fail("bad arguments");

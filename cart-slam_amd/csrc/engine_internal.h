@@ -83,6 +83,10 @@ struct ScheduleState {   // device resident
 void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int n_frames, int update_interval, int reset_interval,
                            const int32_t *hists, cart_plane_params *params_out, hipStream_t s);
 
+struct QMatrix { float q[16]; };
+void launch_reproject(const int16_t *disp, size_t step, size_t fs, const QMatrix &Q, float *xyz, size_t ostep, size_t ofs, int w, int h,
+                      int n_frames, hipStream_t s);
+
 int kernel_count();
 
 }  // namespace cart_amd

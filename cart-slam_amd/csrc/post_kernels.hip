@@ -186,6 +186,28 @@ void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const car
     hipLaunchKernelGGL(classify_dev_kernel, grid, block, 0, s, deriv, step, fs, params_dev, params_stride, planes, pstep, pfs, w, h);
 }
 
+// ------------------------------------------------------------------ depth reprojection
+// depth.cpp:18-19: convertTo(CV_32F, 1/16) + cv::cuda::reprojectImageTo3D(Q): 12 B written per 2 B read, one pass.
+__global__ __launch_bounds__(256) void reproject_kernel(const int16_t *disp, size_t step, size_t fs, QMatrix Q, float *xyz, size_t ostep,
+                                                        size_t ofs, int w, int h) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const float *q = Q.q;
+    const float qx = q[1] * y + q[3], qy = q[5] * y + q[7], qz = q[9] * y + q[11], qw = q[13] * y + q[15];
+    const float d = (float)row_ptr(disp, fs, step, frame, y)[x] * 0.0625f;
+    const float iW = 1.f / (qw + q[12] * x + q[14] * d);
+    float *o = row_ptr(xyz, ofs, ostep, frame, y) + 3 * x;
+    o[0] = (qx + q[0] * x + q[2] * d) * iW;
+    o[1] = (qy + q[4] * x + q[6] * d) * iW;
+    o[2] = (qz + q[8] * x + q[10] * d) * iW;
+}
+
+void launch_reproject(const int16_t *disp, size_t step, size_t fs, const QMatrix &Q, float *xyz, size_t ostep, size_t ofs, int w, int h,
+                      int n_frames, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    hipLaunchKernelGGL(reproject_kernel, grid, block, 0, s, disp, step, fs, Q, xyz, ostep, ofs, w, h);
+}
+
 // ------------------------------------------------------------------ plane-parameter schedule (device replay)
 // One block replays the frames of a batch in id order (planeseg.cu:379-403).  At a refresh frame the 256 bins are
 // ranked in parallel (descending value, ties by ascending index: oracle S11), then thread 0 runs the persistence
@@ -393,6 +415,6 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 16; }
+int kernel_count() { return 17; }
 
 }  // namespace cart_amd

@@ -1,6 +1,6 @@
-// datasource.hpp -- mirrors include/datasource.hpp:9-87: DataElement / StereoDataElement / DataSource.  The KITTI
-// PNG loader and the ZED SDK source are out of scope this round; RawSequenceDataSource reads the same
-// directory shape (image_2/%06d, image_3/%06d) from binary PGM/PPM files.
+// datasource.hpp -- mirrors include/datasource.hpp:9-87 (DataElement / StereoDataElement / DataSource /
+// CameraIntrinsics) and src/sources/kitti.cpp (KITTIDataSource: calib.txt -> Q, image_2 / image_3 frames).  Frames are
+// read from PNG (own zlib-based reader; binary PGM/PPM accepted as well).  The ZED SDK source is out of scope.
 #pragma once
 #include <memory>
 #include <string>
@@ -8,6 +8,11 @@
 #include "image.hpp"
 
 namespace cart {
+
+// The Q matrix OpenCV uses to reproject disparity into 3D (datasource.hpp:11-19), row-major 4x4 float
+struct CameraIntrinsics {
+    float Q[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+};
 
 enum DataElementType { STEREO };
 
@@ -35,17 +40,20 @@ class DataSource {
     virtual bool isFinished() = 0;
     virtual DataElementType getProvidedType() = 0;
     const Size getImageSize() const { return imageSize; }
+    const CameraIntrinsics getCameraIntrinsics() const { return intrinsics; }
 
    protected:
     virtual std::shared_ptr<DataElement> getNextInternal() = 0;
+    CameraIntrinsics intrinsics;
     Size imageSize;
 };
 
 namespace sources {
-// <path>/sequences/<seq>/image_2/%06d.{pgm,ppm} and image_3/... (layout of src/sources/kitti.cpp:89-149)
-class RawSequenceDataSource : public DataSource {
+// <path>/sequences/<seq>/{calib.txt, image_2/%06d.png, image_3/%06d.png} (src/sources/kitti.cpp:89-149).
+// calib.txt is required like in the reference unless the frames are PGM/PPM test images.
+class KITTIDataSource : public DataSource {
    public:
-    RawSequenceDataSource(const std::string &basePath, int sequence);
+    KITTIDataSource(const std::string &basePath, int sequence);
     bool isNextReady() override { return !isFinished(); }
     bool isFinished() override;
     DataElementType getProvidedType() override { return DataElementType::STEREO; }

@@ -10,6 +10,7 @@
 #include <sstream>
 
 #include "cartslam_amd/json.hpp"
+#include "cartslam_amd/modules/depth.hpp"
 #include "cartslam_amd/modules/disparity.hpp"
 #include "cartslam_amd/modules/planeseg.hpp"
 
@@ -56,7 +57,7 @@ std::shared_ptr<DataSource> createDataSource(const Value &cfg) {
     if (!cfg.is_object()) throw std::runtime_error("Data source configuration is not an object.");
     const std::string sourcePath = cfg.at("path").get<std::string>();
     const std::string type = cfg.at("type").get<std::string>();
-    if (type == "kitti") return std::make_shared<sources::RawSequenceDataSource>(sourcePath, get(cfg, "sequence", 0));
+    if (type == "kitti") return std::make_shared<sources::KITTIDataSource>(sourcePath, get(cfg, "sequence", 0));
     if (type == "zed") throw std::runtime_error("Data source type zed needs the proprietary ZED SDK: not supported.");
     throw std::runtime_error("Unknown data source type.");
 }
@@ -76,6 +77,8 @@ void applyModuleConfig(const Value &modulesConfig, std::shared_ptr<System> syste
                                                     // extensions (not in the reference's JSON): OpenCV's createStereoSGM knobs
                                                     get(moduleConfig, "paths", 4), get(moduleConfig, "p1", 10), get(moduleConfig, "p2", 120),
                                                     get(moduleConfig, "uniqueness_ratio", 12));
+        } else if (moduleType == "depth") {  // cartconfig.cpp:138-140
+            system->addModule<DepthModule>();
         } else if (moduleType == "disparity_derivative") {
             system->addModule<ImageDisparityDerivativeModule>();
         } else if (moduleType == "disparity_planeseg") {

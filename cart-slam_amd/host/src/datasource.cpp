@@ -1,5 +1,10 @@
 #include "cartslam_amd/datasource.hpp"
 
+#include <cstring>
+#include <sstream>
+
+#include "cartslam_amd/png.hpp"
+
 #include <cstdio>
 #include <fstream>
 #include <stdexcept>
@@ -7,10 +12,7 @@
 
 namespace cart::sources {
 namespace {
-struct HostImage {
-    int w = 0, h = 0, channels = 0;
-    std::vector<uint8_t> data;
-};
+using cart::util::HostImage;
 
 // binary PGM (P5) / PPM (P6), maxval 255. PPM data is RGB on disk and is swapped to BGR like cv::imread delivers it.
 bool readPnm(const std::string &path, HostImage &out) {
@@ -46,26 +48,86 @@ std::string framePath(const std::string &dir, int cam, int frame, const char *ex
 }
 
 bool readFrame(const std::string &dir, int cam, int frame, HostImage &img) {
-    return readPnm(framePath(dir, cam, frame, "pgm"), img) || readPnm(framePath(dir, cam, frame, "ppm"), img);
+    return cart::util::readPng(framePath(dir, cam, frame, "png"), img) || readPnm(framePath(dir, cam, frame, "pgm"), img) ||
+           readPnm(framePath(dir, cam, frame, "ppm"), img);
+}
+
+bool frameExists(const std::string &dir, int cam, int frame) {
+    for (const char *ext : {"png", "pgm", "ppm"})
+        if (std::ifstream(framePath(dir, cam, frame, ext)).is_open()) return true;
+    return false;
+}
+
+// one "P<id>: 12 numbers" row of calib.txt, tokenised like kitti.cpp:28-86 (the row must hold exactly 12 numbers)
+struct KITTICameraCalibration {
+    int cameraId = -1;
+    float fx = 0, fy = 0, cx = 0, cy = 0, baseline = 0;
+};
+
+bool readCalibLine(std::string line, KITTICameraCalibration &calibration) {
+    size_t pos = line.find(": ");
+    if (pos == std::string::npos) return false;
+    std::string token = line.substr(0, pos);
+    line.erase(0, pos + 2);
+    if (token.empty() || token[0] != 'P') return false;
+    KITTICameraCalibration local;
+    local.cameraId = std::atoi(token.c_str() + 1);
+    float fubx = 0;
+    int i = 0;
+    while ((pos = line.find(" ")) != std::string::npos) {
+        token = line.substr(0, pos);
+        line.erase(0, pos + 1);
+        switch (i) {
+            case 0: local.fx = std::stof(token); break;
+            case 5: local.fy = std::stof(token); break;
+            case 3: fubx = std::stof(token); break;
+            case 2: local.cx = std::stof(token); break;
+            case 6: local.cy = std::stof(token); break;
+        }
+        i++;
+    }
+    if (i != 11) return false;
+    local.baseline = -fubx / local.fx;
+    calibration = local;
+    return true;
 }
 }  // namespace
 
-RawSequenceDataSource::RawSequenceDataSource(const std::string &basePath, int sequence) : DataSource(Size{}) {
+KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence) : DataSource(Size{}) {
     char seq[16];
     std::snprintf(seq, sizeof(seq), "%02d", sequence);
-    dir = basePath + "/sequences/" + seq;  // kitti.cpp:93-96
+    dir = basePath + "/sequences/" + seq;  // kitti.cpp:89-90
+    const std::string calibPath = dir + "/calib.txt";
+    std::ifstream calib(calibPath);
+    KITTICameraCalibration l, r;
+    if (calib.is_open()) {
+        std::string line;
+        while (std::getline(calib, line)) {
+            KITTICameraCalibration c;
+            if (readCalibLine(line, c)) {
+                if (c.cameraId == 2) l = c;
+                else if (c.cameraId == 3) r = c;
+            }
+        }
+        if (l.cameraId != 2 || r.cameraId != 3) throw std::runtime_error("Failed to read calibration file");  // kitti.cpp:126-128
+        float *Q = intrinsics.Q;  // kitti.cpp:139-148 (no resize: scale factors are 1)
+        Q[0 * 4 + 3] = -l.cx;
+        Q[1 * 4 + 3] = -l.cy;
+        Q[2 * 4 + 2] = 0;
+        Q[2 * 4 + 3] = l.fx;
+        Q[3 * 4 + 2] = (float)(-1.0 / l.baseline);
+        Q[3 * 4 + 3] = (l.cx - r.cx) / l.baseline;
+    } else if (std::ifstream(framePath(dir, 2, 0, "png")).is_open()) {
+        throw std::runtime_error("Failed to open calibration file at " + calibPath + ": " + std::strerror(errno));  // kitti.cpp:100-103
+    }
     HostImage first;
     if (!readFrame(dir, 2, 0, first)) throw std::runtime_error("Could not read first frame under " + dir);
     imageSize.width = first.w; imageSize.height = first.h;
 }
 
-bool RawSequenceDataSource::isFinished() {
-    HostImage probe;
-    std::ifstream a(framePath(dir, 2, currentFrame, "pgm")), b(framePath(dir, 2, currentFrame, "ppm"));
-    return !a.is_open() && !b.is_open();
-}
+bool KITTIDataSource::isFinished() { return !frameExists(dir, 2, currentFrame); }
 
-std::shared_ptr<DataElement> RawSequenceDataSource::getNextInternal() {
+std::shared_ptr<DataElement> KITTIDataSource::getNextInternal() {
     HostImage l, r;
     if (!readFrame(dir, 2, currentFrame, l) || !readFrame(dir, 3, currentFrame, r)) throw std::runtime_error("Could not read frame " + std::to_string(currentFrame));
     ++currentFrame;

@@ -9,6 +9,7 @@
 #include <iostream>
 
 #include "cartslam_amd/cartconfig.hpp"
+#include "cartslam_amd/modules/depth.hpp"
 #include "cartslam_amd/modules/planeseg.hpp"
 
 int main(int argc, char **argv) {
@@ -42,7 +43,7 @@ int main(int argc, char **argv) {
         }
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
-                                  CARTSLAM_KEY_PLANE_COMPONENTS};
+                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH};
             for (int id = 1; id <= frames; ++id) {
                 auto run = system->getRunById((uint32_t)id);
                 for (const char *k : keys) {
@@ -53,6 +54,11 @@ int main(int argc, char **argv) {
                     o.write(reinterpret_cast<const char *>(bytes.data()), (std::streamsize)bytes.size());
                 }
             }
+        }
+        if (!dump.empty()) {
+            std::ofstream q(dump + "/Q.bin", std::ios::binary);
+            const cart::CameraIntrinsics K = dataSource->getCameraIntrinsics();
+            q.write(reinterpret_cast<const char *>(K.Q), sizeof(K.Q));
         }
         std::cout << "frames " << frames << " failed " << failed << "\n";
         return failed ? 2 : 0;

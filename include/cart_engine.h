@@ -150,6 +150,13 @@ int cart_plane_classify_dev(cart_engine *engine, int n_frames,
                             const cart_plane_params *params_dev, int params_stride,
                             uint8_t *planes, size_t planes_step, size_t planes_frame_stride, void *stream);
 
+/* replaces: DepthModule::runInternal (src/modules/depth.cpp:9-25): disparity x16 -> float (1/16) and
+ * cv::cuda::reprojectImageTo3D(Q, 3 channels).  Q = row-major 4x4 (HOST pointer, copied), out = CV_32FC3-shaped.
+ * Floating point: results are within 1e-4 relative of the CPU restatement. */
+int cart_reproject_depth(cart_engine *engine, int n_frames,
+                         const int16_t *disp, size_t disp_step, size_t disp_frame_stride, const float Q[16],
+                         float *xyz, size_t xyz_step, size_t xyz_frame_stride, void *stream);
+
 /* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
 

@@ -424,6 +424,22 @@ void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_
     }
 }
 
+/* ------------------------------------------------------------ 8f-2 depth */
+/* src/modules/depth.cpp:18-19 (convertTo 1/16, reprojectImageTo3D); operation order of OpenCV's CUDA kernel */
+void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float Q[16], float *xyz) {
+    for (int y = 0; y < h; y++) {
+        const float qx = Q[1] * y + Q[3], qy = Q[5] * y + Q[7], qz = Q[9] * y + Q[11], qw = Q[13] * y + Q[15];
+        for (int x = 0; x < w; x++) {
+            const float d = (float)disp[(size_t)y * w + x] * 0.0625f;
+            const float iW = 1.f / (qw + Q[12] * x + Q[14] * d);
+            float *o = xyz + ((size_t)y * w + x) * 3;
+            o[0] = (qx + Q[0] * x + Q[2] * d) * iW;
+            o[1] = (qy + Q[4] * x + Q[6] * d) * iW;
+            o[2] = (qz + Q[8] * x + Q[10] * d) * iW;
+        }
+    }
+}
+
 /* --------------------------------------------------------------- a-11 CCL */
 static int uf_find(int32_t *parent, int i) {
     while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }

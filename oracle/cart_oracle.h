@@ -133,6 +133,10 @@ int cart_oracle_histogram_peak_params(const int32_t *hist256, cart_oracle_plane_
 /* a-10 planeseg.cu:160-198 (non-temporal). */
 void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_plane_params *params, uint8_t *planes);
 
+/* SURVEY 8f-2, src/modules/depth.cpp:9-25: disp/16 -> float, cv::cuda::reprojectImageTo3D(Q) (no missing-value
+ * handling): [X Y Z W]^T = Q [x y d 1]^T, out = (X/W, Y/W, Z/W) as float [h][w][3].  Float, compare within 1e-4. */
+void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float Q[16], float *xyz);
+
 /* a-11 (S12). Returns the number of components. */
 int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids);
 

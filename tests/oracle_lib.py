@@ -179,3 +179,23 @@ def ccl(planes):
     ids = np.empty((h, w), np.int32)
     n = lib().cart_oracle_ccl(_p(np.ascontiguousarray(planes, np.uint8)), w, h, _p(ids))
     return ids, n
+
+
+def reproject_depth(disp, Q):
+    h, w = disp.shape
+    Q = np.ascontiguousarray(Q, np.float32).reshape(16)
+    o = np.empty((h, w, 3), np.float32)
+    lib().cart_oracle_reproject_depth(_p(np.ascontiguousarray(disp, np.int16)), w, h, _p(Q), _p(o))
+    return o
+
+
+def kitti_q_matrix(p2, p3):
+    """Q as KITTIDataSource builds it (src/sources/kitti.cpp:28-86, :139-148) from the 12 numbers of the P2 / P3 rows."""
+    fx, cx, fubx, cy = np.float32(p2[0]), np.float32(p2[2]), np.float32(p2[3]), np.float32(p2[6])
+    cxr = np.float32(p3[2])
+    baseline = np.float32(-fubx / fx)
+    Q = np.eye(4, dtype=np.float32)
+    Q[0, 3] = -cx; Q[1, 3] = -cy; Q[2, 2] = 0; Q[2, 3] = fx
+    Q[3, 2] = np.float32(-1.0 / baseline)
+    Q[3, 3] = np.float32((cx - cxr) / baseline)
+    return Q

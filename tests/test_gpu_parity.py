@@ -362,3 +362,19 @@ def test_device_plane_schedule_matches_host_restatement(torch_cuda):
     st = DevicePlaneSchedule(eng, "static", (6, 18, -5, 6, 12, 0))
     assert (st.advance(1, dev(torch, hists[:3])).cpu().numpy() == np.array([(6, 18, -5, 6, 12, 0)] * 3)).all()
     eng.close()
+
+
+def test_reproject_depth_batched(torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    w, h, n = 157, 61, 3
+    d = rng.integers(64, 1200, (n, h, w)).astype(np.int16)
+    d[rng.random(d.shape) < 0.1] = -32768
+    Q = O.kitti_q_matrix([718.856, 0, 607.1928, 45.38225, 0, 718.856, 185.2157, -0.113, 0, 0, 1, 0.0037],
+                         [718.856, 0, 607.1928, -337.2877, 0, 718.856, 185.2157, 2.369, 0, 0, 1, 0.0049])
+    eng = make_engine(w, h, 64, 4, inflight=4)
+    got = eng.reproject_depth(dev(torch, d), Q).cpu().numpy()
+    for f in range(n):
+        exp = O.reproject_depth(d[f], Q)
+        assert np.allclose(got[f], exp, rtol=1e-4, atol=1e-4)  # tolerance of the float path (north_star: 1e-4)
+    eng.close()

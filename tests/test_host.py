@@ -135,3 +135,68 @@ def test_concurrent_frames_disparity(tmp_path):
     assert r.returncode == 0, r.stderr
     for f, (l, rr) in enumerate(frames):
         assert (load(tmp, f + 1, "disparity", np.int16, (h, w)) == O.disparity_module(l, rr, 64, 8, 4)).all(), f"frame {f + 1}"
+
+
+# ---------------------------------------------------------------- KITTI source (PNG + calib.txt) and depth module
+P_ROWS = {  # KITTI odometry calib.txt layout: "P<i>: 12 numbers"
+    0: [718.856, 0.0, 607.1928, 0.0, 0.0, 718.856, 185.2157, 0.0, 0.0, 0.0, 1.0, 0.0],
+    1: [718.856, 0.0, 607.1928, -386.1448, 0.0, 718.856, 185.2157, 0.0, 0.0, 0.0, 1.0, 0.0],
+    2: [718.856, 0.0, 607.1928, 45.38225, 0.0, 718.856, 185.2157, -0.1130887, 0.0, 0.0, 1.0, 0.003779761],
+    3: [718.856, 0.0, 607.1928, -337.2877, 0.0, 718.856, 185.2157, 2.369057, 0.0, 0.0, 1.0, 0.004915215],
+}
+
+
+def make_kitti_png_dataset(tmp, n, w, h, color, seq=3, calib=True):
+    from PIL import Image
+    d = os.path.join(tmp, "kitti", "sequences", "%02d" % seq)
+    os.makedirs(os.path.join(d, "image_2")); os.makedirs(os.path.join(d, "image_3"))
+    frames = []
+    for f in range(n):
+        l, r, _ = synth.make_pair(w, h, 128, 4, seed=777, frame=f, channels=3 if color else 1)
+        for cam, img in ((2, l), (3, r)):
+            pil = Image.fromarray(img[..., ::-1].copy(), "RGB") if color else Image.fromarray(img, "L")
+            pil.save(os.path.join(d, "image_%d" % cam, "%06d.png" % f))
+        frames.append((l, r))
+    if calib:
+        with open(os.path.join(d, "calib.txt"), "w") as fh:
+            for i, row in P_ROWS.items():
+                fh.write("P%d: %s\n" % (i, " ".join(repr(v) for v in row)))
+    src = os.path.join(tmp, "kitti_source.json")
+    json.dump({"type": "kitti", "path": os.path.join(tmp, "kitti"), "sequence": seq}, open(src, "w"))
+    return src, frames
+
+
+def test_kitti_calibration_errors(tmp_path):
+    tmp = str(tmp_path)
+    src, _ = make_kitti_png_dataset(tmp, 1, 64, 32, color=False, calib=False)
+    r = run_exe(src, [], tmp)
+    assert r.returncode != 0 and "Failed to open calibration file" in r.stderr  # kitti.cpp:100-103
+    with open(os.path.join(tmp, "kitti", "sequences", "03", "calib.txt"), "w") as fh:
+        fh.write("P2: 1 2 3\nTr: 0 0 0\n")  # rows without exactly 12 numbers are ignored (kitti.cpp:77-79)
+    r = run_exe(src, [], tmp)
+    assert r.returncode != 0 and "Failed to read calibration file" in r.stderr  # kitti.cpp:126-128
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("color", [True, False])
+def test_kitti_png_source_and_depth(tmp_path, color):
+    """image_2/image_3 PNGs + calib.txt -> Q (src/sources/kitti.cpp:89-149) -> disparity -> depth (src/modules/depth.cpp)."""
+    tmp = str(tmp_path)
+    w, h, n = 300, 100, 2
+    src, frames = make_kitti_png_dataset(tmp, n, w, h, color)
+    os.makedirs(os.path.join(tmp, "dump"))
+    modules = [{"type": "disparity", "num_disparities": 128, "smoothing_radius": 2, "smoothing_iterations": 1}, {"type": "depth"},
+               {"type": "depth_visualization"}]
+    r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump")))
+    assert r.returncode == 0, r.stderr
+    Q = np.fromfile(os.path.join(tmp, "dump", "Q.bin"), np.float32).reshape(4, 4)
+    assert np.array_equal(Q, O.kitti_q_matrix(P_ROWS[2], P_ROWS[3])), Q
+    for f, (l, rr) in enumerate(frames):
+        # cv::imread gives 3-channel BGR even for gray files; BGR2GRAY of a replicated gray is the identity
+        ed = O.disparity_module(l, rr, 128, 4, 4, radius=2, iterations=1)
+        assert (load(tmp, f + 1, "disparity", np.int16, (h, w)) == ed).all(), f"disparity frame {f + 1}"
+        got = load(tmp, f + 1, "depth", np.float32, (h, w, 3))
+        exp = O.reproject_depth(ed, Q)
+        assert np.allclose(got, exp, rtol=1e-4, atol=1e-4), float(np.abs(got - exp).max())  # float path: 1e-4 (north_star)
+        z = got[..., 2][ed > 64]
+        assert np.isfinite(z).all() and (z > 0).all()
