@@ -378,3 +378,33 @@ def test_reproject_depth_batched(torch_cuda):
         exp = O.reproject_depth(d[f], Q)
         assert np.allclose(got[f], exp, rtol=1e-4, atol=1e-4)  # tolerance of the float path (north_star: 1e-4)
     eng.close()
+
+
+def test_randomized_configurations(torch_cuda):
+    """Seeded sweep over sizes / D / paths / min_disparity / P1 / P2 / uniqueness / smoothing, incl. the extremes
+    (uniqueness 0 and 100, min_disparity 0 and 64, width < D, 1-pixel-ragged tiles); every output bit-exact."""
+    torch = torch_cuda
+    rng = np.random.default_rng(20260101)
+    cases = []
+    for i in range(28):
+        D = int(rng.choice([64, 128, 256]))
+        P = int(rng.choice([4, 8]))
+        w = int(rng.integers(16, 420)); h = int(rng.integers(8, 130))
+        md = int(rng.choice([0, 1, 4, 17, 64]))
+        p1 = int(rng.integers(0, 30)); p2 = int(rng.integers(p1, 224))
+        uniq = int(rng.choice([0, 5, 12, 50, 99, 100]))
+        radius = int(rng.choice([-1, 1, 2, 3])); iters = int(rng.choice([1, 2, 5]))
+        ch = int(rng.choice([1, 3]))
+        cases.append((w, h, D, P, md, p1, p2, uniq, radius, iters, ch))
+    cases += [(16, 8, 64, 8, 0, 10, 120, 12, 2, 1, 1), (65, 17, 128, 8, 4, 10, 120, 100, -1, 1, 1), (257, 9, 256, 4, 64, 0, 0, 0, 3, 2, 3)]
+    for k, (w, h, D, P, md, p1, p2, uniq, radius, iters, ch) in enumerate(cases):
+        if k % 3 == 2:  # pure noise images: no structure, many ties / invalid pixels
+            l = rng.integers(0, 256, (h, w) if ch == 1 else (h, w, 3)).astype(np.uint8)
+            r = rng.integers(0, 256, l.shape).astype(np.uint8)
+        else:
+            l, r, _ = synth.make_pair(w, h, D, md, seed=1000 + k, channels=ch)
+        eng = make_engine(w, h, D, P, md, radius=radius, iters=iters, inflight=2, p1=p1, p2=p2, uniqueness_ratio=uniq)
+        got = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+        exp = O.disparity_module(l, r, D, P, md, p1=p1, p2=p2, uniq=uniq, radius=radius, iterations=iters)
+        assert (got == exp).all(), f"case {k}: {(w, h, D, P, md, p1, p2, uniq, radius, iters, ch)}: {int((got != exp).sum())} pixels differ"
+        eng.close()
