@@ -46,6 +46,7 @@ PROTOTYPES = {
     "cart_plane_schedule_advance": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cart_plane_schedule_read": (_i, [_vp, C.POINTER(PlaneParams), C.POINTER(C.c_int32)]),
     "cart_plane_classify_dev": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _i, _vp, _sz, _sz, _vp]),
+    "cart_plane_temporal_vote": (_i, [_vp, _vp, _sz, _i, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "cart_reproject_depth": (_i, [_vp, _i, _vp, _sz, _sz, C.POINTER(C.c_float), _vp, _sz, _sz, _vp]),
     "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),

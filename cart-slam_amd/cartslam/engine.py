@@ -155,6 +155,23 @@ class Engine:
                                                       pp, ps, pfs, _stream_ptr()), "cart_plane_classify_dev")
         return planes
 
+    def plane_temporal_vote(self, planes, prev_planes, flows):
+        """planes: uint8 [h,w]; prev_planes: list of uint8 [h,w]; flows: list of int16 [h,w,2] (S10.5) -- planeseg.cu:199-240."""
+        import torch
+        n = len(prev_planes)
+        if len(flows) != n:
+            raise EngineError("one flow per previous plane image")
+        _, p, s, _ = _geom(planes, 1)
+        out = torch.empty_like(planes)
+        _, op, os_, _ = _geom(out, 1)
+        P = (C.c_void_p * max(n, 1))(); PS = (C.c_size_t * max(n, 1))(); F = (C.c_void_p * max(n, 1))(); FS = (C.c_size_t * max(n, 1))()
+        for k in range(n):
+            _, pp, ps, _ = _geom(prev_planes[k], 1)
+            _, fp, fs, _ = _geom(flows[k], 2)
+            P[k], PS[k], F[k], FS[k] = pp.value, ps, fp.value, fs
+        self._check(self._lib.cart_plane_temporal_vote(self._h, p, s, n, P, PS, F, FS, op, os_, _stream_ptr()), "cart_plane_temporal_vote")
+        return out
+
     # ---- depth module (reference src/modules/depth.cpp:9-25) ----
     def reproject_depth(self, disp, Q):
         import torch

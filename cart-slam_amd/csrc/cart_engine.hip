@@ -577,6 +577,29 @@ int cart_plane_classify_dev(cart_engine *e, int n_frames, const int16_t *deriv, 
     return 0;
 }
 
+int cart_plane_temporal_vote(cart_engine *e, const uint8_t *planes, size_t planes_step, int n_prev, const uint8_t *const *prev_planes,
+                             const size_t *prev_steps, const int16_t *const *flows, const size_t *flow_steps, uint8_t *smoothed,
+                             size_t smoothed_step, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!planes || !smoothed) return fail("NULL pointer");
+    if (n_prev < 0 || n_prev > CART_MAX_TEMPORAL) return fail("n_prev must be in [0, CART_MAX_TEMPORAL]");
+    if (n_prev > 0 && (!prev_planes || !prev_steps || !flows || !flow_steps)) return fail("NULL table");
+    const Geometry &g = e->g;
+    if (planes_step < (size_t)g.w || smoothed_step < (size_t)g.w) return fail("bad step");
+    TemporalArgs t;
+    std::memset(&t, 0, sizeof(t));
+    t.n_prev = n_prev;
+    for (int k = 0; k < n_prev; ++k) {
+        if (!prev_planes[k] || !flows[k]) return fail("NULL entry in the temporal tables");
+        if (prev_steps[k] < (size_t)g.w || flow_steps[k] < (size_t)g.w * 4 || (flow_steps[k] & 3)) return fail("bad step in the temporal tables");
+        t.prev[k] = prev_planes[k]; t.prev_step[k] = prev_steps[k]; t.flow[k] = flows[k]; t.flow_step[k] = flow_steps[k];
+    }
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    launch_temporal_vote(planes, planes_step, t, smoothed, smoothed_step, g.w, g.h, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int cart_reproject_depth(cart_engine *e, int n_frames, const int16_t *disp, size_t disp_step, size_t disp_frame_stride, const float Q[16],
                          float *xyz, size_t xyz_step, size_t xyz_frame_stride, void *stream_) {
     if (!e) return fail("engine is NULL");

@@ -83,6 +83,14 @@ struct ScheduleState {   // device resident
 void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int n_frames, int update_interval, int reset_interval,
                            const int32_t *hists, cart_plane_params *params_out, hipStream_t s);
 
+struct TemporalArgs {
+    int n_prev;
+    const uint8_t *prev[CART_MAX_TEMPORAL];
+    size_t prev_step[CART_MAX_TEMPORAL];
+    const int16_t *flow[CART_MAX_TEMPORAL];
+    size_t flow_step[CART_MAX_TEMPORAL];
+};
+void launch_temporal_vote(const uint8_t *planes, size_t pstep, const TemporalArgs &t, uint8_t *smoothed, size_t sstep, int w, int h, hipStream_t s);
 struct QMatrix { float q[16]; };
 void launch_reproject(const int16_t *disp, size_t step, size_t fs, const QMatrix &Q, float *xyz, size_t ostep, size_t ofs, int w, int h,
                       int n_frames, hipStream_t s);

@@ -186,6 +186,32 @@ void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const car
     hipLaunchKernelGGL(classify_dev_kernel, grid, block, 0, s, deriv, step, fs, params_dev, params_stride, planes, pstep, pfs, w, h);
 }
 
+// ------------------------------------------------------------------ temporal voting (planeseg.cu:199-240)
+__global__ __launch_bounds__(256) void temporal_vote_kernel(const uint8_t *planes, size_t pstep, TemporalArgs t, uint8_t *smoothed, size_t sstep,
+                                                            int w, int h) {
+    const int px = blockIdx.x * 64 + threadIdx.x, py = blockIdx.y * 4 + threadIdx.y;
+    if (px >= w || py >= h) return;
+    int votes[3] = {0, 0, 0};
+    votes[planes[(size_t)py * pstep + px]]++;
+    int x = px, y = py;
+    for (int k = 0; k < t.n_prev; ++k) {
+        // the reference reads the flow at the ORIGINAL pixel, not at the tracked position (:212-213)
+        const short2 f = *reinterpret_cast<const short2 *>(reinterpret_cast<const uint8_t *>(t.flow[k]) + (size_t)py * t.flow_step[k] + (size_t)px * 4);
+        x -= (int16_t)(f.x >> 5);  // S10.5 -> whole pixels (:216-217)
+        y -= (int16_t)(f.y >> 5);
+        if (x < 0 || y < 0 || x >= w || y >= h) continue;
+        votes[t.prev[k][(size_t)y * t.prev_step[k] + x]]++;
+    }
+    int best = votes[CART_PLANE_HORIZONTAL] > votes[CART_PLANE_VERTICAL] ? CART_PLANE_HORIZONTAL : CART_PLANE_VERTICAL;
+    if (votes[best] == 0) best = CART_PLANE_UNKNOWN;
+    smoothed[(size_t)py * sstep + px] = (uint8_t)best;
+}
+
+void launch_temporal_vote(const uint8_t *planes, size_t pstep, const TemporalArgs &t, uint8_t *smoothed, size_t sstep, int w, int h, hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+    hipLaunchKernelGGL(temporal_vote_kernel, grid, block, 0, s, planes, pstep, t, smoothed, sstep, w, h);
+}
+
 // ------------------------------------------------------------------ depth reprojection
 // depth.cpp:18-19: convertTo(CV_32F, 1/16) + cv::cuda::reprojectImageTo3D(Q): 12 B written per 2 B read, one pass.
 __global__ __launch_bounds__(256) void reproject_kernel(const int16_t *disp, size_t step, size_t fs, QMatrix Q, float *xyz, size_t ostep,
@@ -415,6 +441,6 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 17; }
+int kernel_count() { return 18; }
 
 }  // namespace cart_amd

@@ -41,6 +41,7 @@ class DataSource {
     virtual DataElementType getProvidedType() = 0;
     const Size getImageSize() const { return imageSize; }
     const CameraIntrinsics getCameraIntrinsics() const { return intrinsics; }
+    virtual std::string getPath() const { return std::string(); }  // directory of the sequence, if the source has one
 
    protected:
     virtual std::shared_ptr<DataElement> getNextInternal() = 0;
@@ -57,6 +58,7 @@ class KITTIDataSource : public DataSource {
     bool isNextReady() override { return !isFinished(); }
     bool isFinished() override;
     DataElementType getProvidedType() override { return DataElementType::STEREO; }
+    std::string getPath() const override { return dir; }
 
    protected:
     std::shared_ptr<DataElement> getNextInternal() override;

@@ -1,6 +1,8 @@
 // modules/planeseg.hpp -- mirrors include/modules/planeseg.hpp:15-162 (keys, Plane, PlaneParameters, the two
-// parameter providers, DisparityPlaneSegmentationModule).  Temporal smoothing needs the optical-flow module, which is
-// NVIDIA fixed-function hardware in the reference and out of scope: requesting it throws at construction.
+// parameter providers, DisparityPlaneSegmentationModule incl. temporal smoothing).  Temporal smoothing consumes the
+// "optflow" key (S10.5 CV_16SC2); the reference's provider of that key is NVIDIA fixed-function hardware
+// (src/modules/optflow.cpp) and out of scope, so any module providing "optflow" will do (OpticalFlowFileModule below
+// replays flow fields from files).
 #pragma once
 #include <mutex>
 #include <shared_mutex>
@@ -12,6 +14,7 @@
 #define CARTSLAM_KEY_PLANES_UNSMOOTHED "planes_unsmoothed"
 #define CARTSLAM_KEY_PLANE_PARAMETERS "plane_parameters"
 #define CARTSLAM_KEY_DISPARITY_DERIVATIVE_HIST "disp_derivative_histogram"
+#define CARTSLAM_KEY_OPTFLOW "optflow"  // include/modules/optflow.hpp
 #define CARTSLAM_KEY_PLANE_COMPONENTS "plane_components"  // new: connected-component ids (no reference counterpart)
 #define CARTSLAM_PLANE_COUNT 3
 #define CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT 3
@@ -76,6 +79,8 @@ class DisparityPlaneSegmentationModule : public SyncWrapperSystemModule {
    private:
     void updatePlaneParameters(System &system, SystemRunData &data);  // planeseg.cu:379-403
 
+    const bool useTemporalSmoothing;
+    const unsigned int temporalSmoothingDistance;
     const int updateInterval;
     const int resetInterval;
     const bool labelComponents;
@@ -84,5 +89,14 @@ class DisparityPlaneSegmentationModule : public SyncWrapperSystemModule {
     int32_t *derivativeHistogram = nullptr;  // persistent 256-bin device histogram (planeseg.hpp:160-161)
     std::mutex engineMutex;
     std::shared_ptr<EngineHandle> engine;
+};
+
+typedef int16_t optical_flow_t;  // S10.5, two channels (include/modules/optflow.hpp)
+
+// Stand-in provider of "optflow": <sequence dir>/flow/%06d.bin, raw int16 [h][w][2], frame index = run id - 1.
+class OpticalFlowFileModule : public SyncWrapperSystemModule {
+   public:
+    OpticalFlowFileModule() : SyncWrapperSystemModule("ImageOpticalFlow") { this->providesData.push_back(CARTSLAM_KEY_OPTFLOW); }
+    system_data_t runInternal(System &system, SystemRunData &data) override;
 };
 }  // namespace cart

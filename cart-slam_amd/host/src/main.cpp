@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         }
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
-                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH};
+                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED};
             for (int id = 1; id <= frames; ++id) {
                 auto run = system->getRunById((uint32_t)id);
                 for (const char *k : keys) {

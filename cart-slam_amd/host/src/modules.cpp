@@ -1,6 +1,7 @@
 // modules.cpp -- the three hot-path modules on top of the C ABI (include/cart_engine.h).
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <cstring>
 
 #include "cartslam_amd/modules/depth.hpp"
@@ -107,12 +108,21 @@ system_data_t DepthModule::runInternal(System &system, SystemRunData &data) {
 
 // ---------------------------------------------------------------- plane labels (planeseg.cu:246-458)
 DisparityPlaneSegmentationModule::DisparityPlaneSegmentationModule(std::shared_ptr<PlaneParameterProvider> provider, const int updateInterval, const int resetInterval,
-                                                                   const bool useTemporalSmoothing, const unsigned int, const bool labelComponents)
-    : SyncWrapperSystemModule("PlaneSegmentation"), updateInterval(updateInterval), resetInterval(resetInterval), labelComponents(labelComponents), planeParameterProvider(provider) {
-    if (useTemporalSmoothing)
-        throw std::runtime_error("use_temporal_smoothing needs the optical-flow module (NVIDIA fixed-function hardware in the reference): not supported");
+                                                                   const bool useTemporalSmoothing, const unsigned int temporalSmoothingDistance, const bool labelComponents)
+    : SyncWrapperSystemModule("PlaneSegmentation"), useTemporalSmoothing(useTemporalSmoothing), temporalSmoothingDistance(temporalSmoothingDistance),
+      updateInterval(updateInterval), resetInterval(resetInterval), labelComponents(labelComponents), planeParameterProvider(provider) {
+    if (useTemporalSmoothing && (temporalSmoothingDistance < 1 || temporalSmoothingDistance > CART_MAX_TEMPORAL))
+        throw std::runtime_error("temporal_smoothing_distance must be in [1, 8]");
     this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY));
+    if (useTemporalSmoothing) {  // planeseg.hpp:128-137: optical flow and the earlier frames' unsmoothed planes
+        this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_OPTFLOW));
+        for (size_t i = 1; i <= this->temporalSmoothingDistance; i++) {
+            this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_PLANES_UNSMOOTHED, -(int)i));
+            if ((i + 1) <= this->temporalSmoothingDistance) this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_OPTFLOW, -(int)i));
+        }
+    }
     this->providesData.push_back(CARTSLAM_KEY_PLANES);
+    if (useTemporalSmoothing) this->providesData.push_back(CARTSLAM_KEY_PLANES_UNSMOOTHED);
     if (labelComponents) this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENTS);
 }
 
@@ -150,6 +160,35 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
     ScopedStream stream;
     if (cart_plane_classify(eng->get(), 1, derivatives->ptr<int16_t>(), derivatives->step, 0, &cp, 0, planes->ptr<uint8_t>(), planes->step, 0, stream.s) != 0)
         eng->fail("cart_plane_classify");
+    std::shared_ptr<image_t> smoothed;
+    std::vector<std::shared_ptr<image_t>> keepAlive;
+    if (this->useTemporalSmoothing && data.id > 1) {  // planeseg.cu:303-347
+        smoothed = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_8UC1);
+        const uint8_t *prevPlanes[CART_MAX_TEMPORAL];
+        size_t prevSteps[CART_MAX_TEMPORAL];
+        const int16_t *flows[CART_MAX_TEMPORAL];
+        size_t flowSteps[CART_MAX_TEMPORAL];
+        int previousPlaneCount = 0;
+        auto optFlowCurr = data.getData<image_t>(CARTSLAM_KEY_OPTFLOW);
+        keepAlive.push_back(optFlowCurr);
+        flows[0] = optFlowCurr->ptr<int16_t>(); flowSteps[0] = optFlowCurr->step;
+        for (int i = 1; i <= (int)this->temporalSmoothingDistance; i++) {
+            if ((int64_t)data.id - i <= 0) break;
+            auto relativeRun = data.getRelativeRun((int8_t)-i);
+            auto prev = relativeRun->getData<image_t>(CARTSLAM_KEY_PLANES_UNSMOOTHED);
+            keepAlive.push_back(prev);
+            prevPlanes[previousPlaneCount] = prev->ptr<uint8_t>(); prevSteps[previousPlaneCount] = prev->step;
+            previousPlaneCount++;
+            if (relativeRun->id > 1 && previousPlaneCount < (int)this->temporalSmoothingDistance) {
+                auto optFlow = relativeRun->getData<image_t>(CARTSLAM_KEY_OPTFLOW);
+                keepAlive.push_back(optFlow);
+                flows[previousPlaneCount] = optFlow->ptr<int16_t>(); flowSteps[previousPlaneCount] = optFlow->step;
+            }
+        }
+        if (cart_plane_temporal_vote(eng->get(), planes->ptr<uint8_t>(), planes->step, previousPlaneCount, prevPlanes, prevSteps, flows, flowSteps,
+                                     smoothed->ptr<uint8_t>(), smoothed->step, stream.s) != 0)
+            eng->fail("cart_plane_temporal_vote");
+    }
     std::shared_ptr<image_t> components;
     if (labelComponents) {
         components = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_32SC1);
@@ -157,10 +196,31 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
             eng->fail("cart_plane_ccl");
     }
     stream.wait();
-    if (labelComponents)
-        return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(planes)),
-                                 std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
-    return MODULE_RETURN(CARTSLAM_KEY_PLANES, planes);
+    system_data_t out;
+    if (this->useTemporalSmoothing) {  // planeseg.cu:361-374: frame 1 returns the same image under both keys
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(data.id == 1 ? planes : smoothed)));
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANES_UNSMOOTHED), std::shared_ptr<void>(planes)));
+    } else {
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(planes)));
+    }
+    if (labelComponents) out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
+    return out;
+}
+
+system_data_t OpticalFlowFileModule::runInternal(System &system, SystemRunData &data) {
+    const std::string dir = system.getDataSource()->getPath();
+    const Size size = system.getDataSource()->getImageSize();
+    char name[64];
+    std::snprintf(name, sizeof(name), "/flow/%06u.bin", data.id - 1);
+    std::vector<int16_t> host((size_t)size.width * size.height * 2);
+    FILE *f = std::fopen((dir + name).c_str(), "rb");
+    if (!f) throw std::runtime_error("Could not open optical flow file " + dir + name);
+    const size_t got = std::fread(host.data(), sizeof(int16_t), host.size(), f);
+    std::fclose(f);
+    if (got != host.size()) throw std::runtime_error("Truncated optical flow file " + dir + name);
+    auto flow = std::make_shared<image_t>(size.height, size.width, CV_16SC2);
+    flow->upload(host.data(), (size_t)size.width * 4);
+    return MODULE_RETURN(CARTSLAM_KEY_OPTFLOW, flow);
 }
 
 void DisparityPlaneSegmentationModule::updatePlaneParameters(System &system, SystemRunData &data) {

@@ -113,6 +113,16 @@ int cart_plane_classify(cart_engine *engine, int n_frames,
                         const cart_plane_params *params, int params_per_frame,
                         uint8_t *planes, size_t planes_step, size_t planes_frame_stride, void *stream);
 
+/* replaces: the temporal-voting branch of classifyPlanes (planeseg.cu:199-240) with the tables the module builds at
+ * :303-347: prev_planes[k] = unsmoothed planes of frame id-(k+1), flows[k] = optical flow of frame id-k (CV_16SC2-shaped,
+ * S10.5 fixed point).  n_prev <= 8.  The pointer arrays are HOST arrays of DEVICE pointers.  Single frame: temporal
+ * smoothing makes frames depend on each other, so it does not shard. */
+#define CART_MAX_TEMPORAL 8
+int cart_plane_temporal_vote(cart_engine *engine, const uint8_t *planes, size_t planes_step, int n_prev,
+                             const uint8_t *const *prev_planes, const size_t *prev_steps,
+                             const int16_t *const *flows, const size_t *flow_steps,
+                             uint8_t *smoothed, size_t smoothed_step, void *stream);
+
 /* New stage (no reference counterpart; BASELINE config 3 "plane CCL"): 4-connected components of
  * the label map over labels {0,1}; id = smallest linear index y*width+x of the component,
  * UNKNOWN pixels -> -1.  n_components (device, one int32 per frame) may be NULL. */

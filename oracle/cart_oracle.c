@@ -424,6 +424,27 @@ void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_
     }
 }
 
+/* ------------------------------------------------- a-10 temporal voting */
+void cart_oracle_temporal_vote(const uint8_t *planes, int w, int h, int n_prev, const uint8_t *const *prev_planes,
+                               const int16_t *const *flows, uint8_t *smoothed) {
+    for (int py = 0; py < h; py++)
+        for (int px = 0; px < w; px++) {
+            int votes[3] = {0, 0, 0};
+            votes[planes[(size_t)py * w + px]]++;
+            int x = px, y = py;
+            for (int k = 0; k < n_prev; k++) {
+                int16_t fx = flows[k][((size_t)py * w + px) * 2 + 0], fy = flows[k][((size_t)py * w + px) * 2 + 1];
+                fx = (int16_t)(fx >> 5); fy = (int16_t)(fy >> 5);
+                x -= fx; y -= fy;
+                if (x < 0 || y < 0 || x >= w || y >= h) continue;
+                votes[prev_planes[k][(size_t)y * w + x]]++;
+            }
+            int best = votes[0] > votes[1] ? 0 : 1;
+            if (votes[best] == 0) best = 2;
+            smoothed[(size_t)py * w + px] = (uint8_t)best;
+        }
+}
+
 /* ------------------------------------------------------------ 8f-2 depth */
 /* src/modules/depth.cpp:18-19 (convertTo 1/16, reprojectImageTo3D); operation order of OpenCV's CUDA kernel */
 void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float Q[16], float *xyz) {

@@ -133,6 +133,13 @@ int cart_oracle_histogram_peak_params(const int32_t *hist256, cart_oracle_plane_
 /* a-10 planeseg.cu:160-198 (non-temporal). */
 void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_plane_params *params, uint8_t *planes);
 
+/* a-10 temporal branch, planeseg.cu:199-240: votes[plane]++; walk back k = 0..n_prev-1: the flow (S10.5, 2 x s16
+ * interleaved, flows[k]) is read at the ORIGINAL pixel (as the reference does, :212-213), >>5, subtracted from the
+ * running position; inside the image -> votes[prev_planes[k][y][x]]++ (outside: skipped, position kept).
+ * out = votes[H] > votes[V] ? H : V, UNKNOWN if that count is 0 (:235-238). */
+void cart_oracle_temporal_vote(const uint8_t *planes, int w, int h, int n_prev, const uint8_t *const *prev_planes,
+                               const int16_t *const *flows, uint8_t *smoothed);
+
 /* SURVEY 8f-2, src/modules/depth.cpp:9-25: disp/16 -> float, cv::cuda::reprojectImageTo3D(Q) (no missing-value
  * handling): [X Y Z W]^T = Q [x y d 1]^T, out = (X/W, Y/W, Z/W) as float [h][w][3].  Float, compare within 1e-4. */
 void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float Q[16], float *xyz);

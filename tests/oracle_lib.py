@@ -199,3 +199,15 @@ def kitti_q_matrix(p2, p3):
     Q[3, 2] = np.float32(-1.0 / baseline)
     Q[3, 3] = np.float32((cx - cxr) / baseline)
     return Q
+
+
+def temporal_vote(planes, prev_planes, flows):
+    h, w = planes.shape
+    n = len(prev_planes)
+    pp = [np.ascontiguousarray(a, np.uint8) for a in prev_planes]
+    ff = [np.ascontiguousarray(a, np.int16) for a in flows]
+    P = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in pp])
+    F = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in ff])
+    o = np.empty((h, w), np.uint8)
+    lib().cart_oracle_temporal_vote(_p(np.ascontiguousarray(planes, np.uint8)), w, h, n, P, F, _p(o))
+    return o

@@ -408,3 +408,19 @@ def test_randomized_configurations(torch_cuda):
         exp = O.disparity_module(l, r, D, P, md, p1=p1, p2=p2, uniq=uniq, radius=radius, iterations=iters)
         assert (got == exp).all(), f"case {k}: {(w, h, D, P, md, p1, p2, uniq, radius, iters, ch)}: {int((got != exp).sum())} pixels differ"
         eng.close()
+
+
+def test_temporal_vote(torch_cuda):
+    """classifyPlanes' temporal branch (planeseg.cu:199-240) with random planes / S10.5 flows, 0..3 previous frames,
+    flows large enough to leave the image and negative flows (arithmetic >> 5)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(33)
+    w, h = 139, 53
+    eng = make_engine(w, h, 64, 4)
+    for n_prev in (0, 1, 2, 3):
+        planes = rng.integers(0, 3, (h, w)).astype(np.uint8)
+        prev = [rng.integers(0, 3, (h, w)).astype(np.uint8) for _ in range(n_prev)]
+        flows = [(rng.integers(-40, 40, (h, w, 2)) * rng.integers(1, 64, (h, w, 2))).astype(np.int16) for _ in range(n_prev)]
+        got = eng.plane_temporal_vote(dev(torch, planes), [dev(torch, p) for p in prev], [dev(torch, f) for f in flows]).cpu().numpy()
+        assert (got == O.temporal_vote(planes, prev, flows)).all(), n_prev
+    eng.close()

@@ -200,3 +200,46 @@ def test_kitti_png_source_and_depth(tmp_path, color):
         assert np.allclose(got, exp, rtol=1e-4, atol=1e-4), float(np.abs(got - exp).max())  # float path: 1e-4 (north_star)
         z = got[..., 2][ed > 64]
         assert np.isfinite(z).all() and (z > 0).all()
+
+
+@pytest.mark.gpu
+def test_temporal_smoothing_frame_loop(tmp_path):
+    """use_temporal_smoothing through the module API: cross-frame dependencies (planes_unsmoothed of runs -1..-3, optflow
+    of runs 0..-2; include/modules/planeseg.hpp:127-143) and the tables of planeseg.cu:303-347, flow replayed from files."""
+    tmp = str(tmp_path)
+    w, h, n, dist = 200, 72, 6, 3
+    src, frames = make_dataset(tmp, n, w, h)
+    fdir = os.path.join(tmp, "dataset", "sequences", "00", "flow")
+    os.makedirs(fdir)
+    rng = np.random.default_rng(8)
+    flows = []
+    for f in range(n):
+        fl = (rng.integers(-6, 7, (h, w, 2)) * 32 + rng.integers(0, 32, (h, w, 2))).astype(np.int16)
+        fl.tofile(os.path.join(fdir, "%06d.bin" % f)); flows.append(fl)
+    os.makedirs(os.path.join(tmp, "dump"))
+    static = {"type": "static", "horizontal_range_min": 6, "horizontal_range_max": 18, "vertical_range_min": -5, "vertical_range_max": 6}
+    modules = [{"type": "disparity", "num_disparities": 64, "paths": 8, "smoothing_radius": 2, "smoothing_iterations": 1},
+               {"type": "optflow_file"},
+               {"type": "disparity_planeseg", "parameter_provider": static, "use_temporal_smoothing": True, "temporal_smoothing_distance": dist}]
+    r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump"), "--sequential", "1"))
+    assert r.returncode == 0, r.stderr
+    params = (6, 18, -5, 6, 12, 0)
+    unsm = []
+    for f, (l, rr) in enumerate(frames):
+        fid = f + 1
+        ed = O.disparity_module(l, rr, 64, 8, 4, radius=2, iterations=1)
+        pd, _ = O.plane_derivative(ed)
+        cur = O.classify(pd, params)
+        unsm.append(cur)
+        assert (load(tmp, fid, "planes_unsmoothed", np.uint8, (h, w)) == cur).all(), f"unsmoothed frame {fid}"
+        if fid == 1:
+            exp = cur
+        else:
+            k = min(dist, fid - 1)
+            prev = [unsm[f - i] for i in range(1, k + 1)]          # frames id-1, id-2, ...
+            fl = [flows[f - i] for i in range(0, k)]               # flow of frames id, id-1, ...
+            exp = O.temporal_vote(cur, prev, fl)
+        assert (load(tmp, fid, "planes", np.uint8, (h, w)) == exp).all(), f"smoothed frame {fid}"
+    # the reference's own provider of "optflow" is NVIDIA hardware: asking for it must fail loudly
+    r = run_exe(src, [{"type": "optflow"}], tmp)
+    assert r.returncode != 0 and "not supported" in r.stderr
