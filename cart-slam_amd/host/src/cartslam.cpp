@@ -2,6 +2,8 @@
 
 #include <algorithm>
 
+#include "cartslam_amd/timing.hpp"
+
 namespace cart {
 
 // src/modules/module.cpp:7-19: post runInternal to a worker and hand back its future
@@ -57,12 +59,15 @@ std::future<void> System::run() {
     }
     auto mods = modules;
     return std::async(std::launch::async, [this, run, mods]() {
+        auto frameTiming = timing::initTiming("Frame", run->id);  // cartslam.cpp:245-251
+        timing::startTiming(frameTiming);
         std::exception_ptr first;
         std::vector<std::future<void>> done;
         for (const auto &m : mods) {
             // every module gets its own waiter: dependencies first (cartslam.cpp:96-167), then the module, then the
             // returned (key, ptr) pairs go onto the frame's blackboard (cartslam.cpp:279-301)
             done.push_back(std::async(std::launch::async, [this, run, m]() {
+                auto moduleTiming = timing::initTiming(m->name, run->id);  // cartslam.cpp:259-262: init before the dependency wait
                 std::vector<std::string> same_frame;
                 for (const auto &d : m->getRequiredData()) {
                     if (d.runOffset == 0) { same_frame.push_back(d.name); continue; }
@@ -71,13 +76,16 @@ std::future<void> System::run() {
                     catch (...) { if (!d.optional) throw; }
                 }
                 run->waitForData(same_frame);
+                timing::startTiming(moduleTiming);  // :270
                 system_data_t out = m->run(*this, *run).get();
                 for (const auto &kv : out) run->insertData(kv);
+                timing::endTiming(moduleTiming);  // :290
             }));
         }
         for (auto &f : done) {
             try { f.get(); } catch (...) { if (!first) first = std::current_exception(); }
         }
+        timing::endTiming(frameTiming);
         {
             std::unique_lock<std::mutex> lock(runMutex);
             --activeRuns;

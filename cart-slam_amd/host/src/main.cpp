@@ -1,4 +1,4 @@
-// cart_slam_amd <source.json> <modules.json> [--frames N] [--dump DIR] [--sequential 1]
+// cart_slam_amd <source.json> <modules.json> [--frames N] [--dump DIR] [--sequential 1] [--timing FILE.csv]
 // (--sequential 1 finishes every frame before the next starts: the cumulative plane histogram then sees the frames in id
 //  order, which the reference's concurrent frame loop does not guarantee)
 // Frame loop of the reference's src/main.cpp:8-63 without logging/UI; --dump writes every frame's blackboard images as
@@ -10,6 +10,7 @@
 
 #include "cartslam_amd/cartconfig.hpp"
 #include "cartslam_amd/modules/depth.hpp"
+#include "cartslam_amd/timing.hpp"
 #include "cartslam_amd/modules/planeseg.hpp"
 
 int main(int argc, char **argv) {
@@ -24,6 +25,7 @@ int main(int argc, char **argv) {
         if (!std::strcmp(argv[i], "--frames")) maxFrames = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--dump")) dump = argv[i + 1];
         else if (!std::strcmp(argv[i], "--sequential")) sequential = std::atoi(argv[i + 1]) != 0;
+        else if (!std::strcmp(argv[i], "--timing")) cart::timing::Sink::instance().open(argv[i + 1]);
     }
     try {
         auto dataSource = cart::config::readDataSourceConfig(argv[1]);

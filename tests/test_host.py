@@ -131,8 +131,13 @@ def test_concurrent_frames_disparity(tmp_path):
     w, h, n = 320, 96, 14
     src, frames = make_dataset(tmp, n, w, h)
     os.makedirs(os.path.join(tmp, "dump"))
-    r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "paths": 8}], tmp, ("--dump", os.path.join(tmp, "dump")))
+    tcsv = os.path.join(tmp, "timing.csv")
+    r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "paths": 8}], tmp, ("--dump", os.path.join(tmp, "dump"), "--timing", tcsv))
     assert r.returncode == 0, r.stderr
+    rows = [ln.strip().split(";") for ln in open(tcsv)]
+    assert rows[0][:6] == ["name", "run_id", "time_init", "time_start", "time_end", "duration_ms"]  # include/timing.hpp:59
+    assert sorted(int(x[1]) for x in rows[1:] if x[0] == "ImageDisparity") == list(range(1, n + 1))
+    assert sum(1 for x in rows[1:] if x[0] == "Frame") == n
     for f, (l, rr) in enumerate(frames):
         assert (load(tmp, f + 1, "disparity", np.int16, (h, w)) == O.disparity_module(l, rr, 64, 8, 4)).all(), f"frame {f + 1}"
 
