@@ -44,7 +44,8 @@ def _geom(t, inner):
 
 
 class Engine:
-    """One engine = one (width, height, D, paths, ...) configuration on one GPU."""
+    """One engine = one (width, height, D, paths, ...) configuration on one GPU.
+    num_disparities=0, paths=0 gives a geometry-only engine for the post-SGM entry points."""
 
     def __init__(self, width, height, num_disparities=256, paths=4, min_disparity=4, p1=10, p2=120,
                  uniqueness_ratio=12, smoothing_radius=-1, smoothing_iterations=5, max_inflight=12, device_id=0):

@@ -68,6 +68,7 @@ struct cart_engine {
     std::condition_variable cv;
     std::vector<Slot> slots;
     int chunk_frames = 16;          // frames per launch sequence inside one batched call
+    bool post_only = false;         // no SGM workspaces (num_disparities == 0)
     bool timing = false;
     std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
     size_t ring_calls = 0;
@@ -157,9 +158,10 @@ void build_agg_args(cart_engine *e) {
 int validate(const cart_engine_params *p) {
     if (!p) return fail("params is NULL");
     if (p->width < 16 || p->height < 8 || p->width > 16384 || p->height > 16384) return fail("unsupported image size");
-    if (!(p->num_disparities == 64 || p->num_disparities == 128 || p->num_disparities == 256))
+    const bool post_only = p->num_disparities == 0 && p->paths == 0;
+    if (!post_only && !(p->num_disparities == 64 || p->num_disparities == 128 || p->num_disparities == 256))
         return fail("num_disparities must be 64, 128 or 256");
-    if (!(p->paths == 4 || p->paths == 8)) return fail("paths must be 4 or 8");
+    if (!post_only && !(p->paths == 4 || p->paths == 8)) return fail("paths must be 4 or 8");
     if (p->min_disparity < 0 || p->min_disparity > 64) return fail("min_disparity must be in [0, 64]");
     if (p->p1 < 0 || p->p2 < p->p1 || p->p2 + 31 > 255) return fail("need 0 <= p1 <= p2 and 31 + p2 <= 255");
     if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100) return fail("uniqueness_ratio must be in [0, 100]");
@@ -214,6 +216,18 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     e->uniq = (float)(100 - params->uniqueness_ratio) / 100.0f;  // oracle S5
     const size_t n = (size_t)params->max_inflight;
     int rc = 0;
+    e->post_only = g.D == 0;
+    if (e->post_only) {  // geometry-only engine: interpolate ping-pong and CCL links are all the post stages need
+        rc |= dev_alloc(&e->tmp_a, n * g.npx);
+        rc |= dev_alloc(&e->tmp_b, n * g.npx);
+        rc |= dev_alloc(&e->ccl_work, n * g.npx);
+        if (rc) { cart_engine_destroy(e); return -1; }
+        e->slots.resize(n);
+        for (auto &s : e->slots)
+            if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) { cart_engine_destroy(e); return fail("hipEventCreate failed"); }
+        *out = e;
+        return 0;
+    }
     rc |= dev_alloc(&e->gray_l, n * g.npx);
     rc |= dev_alloc(&e->gray_r, n * g.npx);
     // the cooperative window loads of waves whose leading scan lines are still outside the image touch
@@ -323,6 +337,7 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
                                  size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
                                  size_t out_frame_stride, void *stream_) {
     if (!e) return fail("engine is NULL");
+    if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (!left || !right || !out) return fail("NULL image pointer");
     if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
     const Geometry &g = e->g;
@@ -676,6 +691,7 @@ int cart_find_plane_params(const int32_t hist[256], cart_plane_params *io) {
 
 int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, size_t bytes) {
     if (!e || !host_dst) return fail("bad arguments");
+    if (e->post_only) return fail("this engine has no SGM workspaces");
     const Geometry &g = e->g;
     const int slot = g_last_slot + frame_slot;
     if (frame_slot < 0 || slot >= (int)e->slots.size()) return fail("frame_slot out of range");

@@ -69,9 +69,9 @@ ImageDisparityDerivativeModule::ImageDisparityDerivativeModule() : SyncWrapperSy
 
 static std::shared_ptr<EngineHandle> postEngine(std::mutex &mu, std::shared_ptr<EngineHandle> &slot, const image_t &disp) {
     std::lock_guard<std::mutex> lk(mu);
-    if (!slot) {  // the post stages only need the geometry; SGM workspaces are sized for the smallest configuration
+    if (!slot) {  // the post stages only need the geometry: num_disparities = paths = 0 -> no SGM workspaces
         Size res; res.width = disp.cols; res.height = disp.rows;
-        cart_engine_params p = paramsFor(res, 0, 64, -1, 0, 4, 10, 120, 12);
+        cart_engine_params p = paramsFor(res, 0, 0, -1, 0, 0, 10, 120, 12);
         slot = std::make_shared<EngineHandle>(res, p);
     }
     return slot;

@@ -42,7 +42,8 @@ typedef struct {
     int device_id;
     int width, height;        /* DataSource::getImageSize(), include/datasource.hpp:75 */
     int min_disparity;        /* "min_disparity", default 4; 0..64 supported */
-    int num_disparities;      /* "num_disparities": 64 | 128 | 256 */
+    int num_disparities;      /* "num_disparities": 64 | 128 | 256; 0 (with paths 0) = geometry-only engine for the
+                                 post-SGM entry points: no SGM workspaces, cart_compute_disparity* fail */
     int paths;                /* 4 (MODE_HH4) | 8 (MODE_HH) */
     int p1, p2;               /* 10, 120 ; 31 + p2 must fit u8 */
     int uniqueness_ratio;     /* disparity.hpp:32 -> 12 */

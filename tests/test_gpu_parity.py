@@ -192,6 +192,27 @@ def test_plane_stages(torch_cuda):
     eng.close()
 
 
+def test_geometry_only_engine(torch_cuda):
+    """num_disparities = paths = 0: post-stage entry points work, the SGM entry point refuses loudly."""
+    torch = torch_cuda
+    from cartslam import Engine, EngineError
+    w, h = 150, 40
+    eng = Engine(w, h, num_disparities=0, paths=0, max_inflight=2)
+    rng = np.random.default_rng(4)
+    d = rng.integers(64, 300, (h, w)).astype(np.int16)
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    pd = eng.plane_derivative_hist(dev(torch, d), hist)
+    eb, eh = O.plane_derivative(d)
+    assert (pd.cpu().numpy() == eb).all() and (hist.cpu().numpy() == eh).all()
+    ids, n = eng.plane_ccl(eng.plane_classify(pd, (6, 18, -5, 6, 12, 0)))
+    eids, en = O.ccl(O.classify(eb, (6, 18, -5, 6, 12, 0)))
+    assert (ids.cpu().numpy() == eids).all() and int(n.item()) == en
+    img = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    with pytest.raises(EngineError):
+        eng.compute_disparity(img, img)
+    eng.close()
+
+
 def test_ccl_hard_shapes(torch_cuda):
     """Spirals / combs / checkerboards: long union-find chains and many tiny components."""
     torch = torch_cuda
