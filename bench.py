@@ -61,8 +61,20 @@ def cpu_baseline(w, h, D, P, seconds_budget=12.0):
         el = time.perf_counter() - t0
         if el > seconds_budget:
             break
-    return {"value": round(n / el, 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} pair(s) {w}x{h} D={D} {P} paths + plane labelling + CCL, OpenMP oracle, {el:.1f} s"}
+    out = {"value": round(n / el, 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
+           "sample": f"{n} pair(s) {w}x{h} D={D} {P} paths + plane labelling + CCL, OpenMP oracle, {el:.1f} s"}
+    try:  # secondary, BASELINE.md section 4: only if OpenCV happens to be installed (a DIFFERENT algorithm: timing only)
+        import cv2
+        sgbm = cv2.StereoSGBM_create(minDisparity=4, numDisparities=D, blockSize=3, uniquenessRatio=12,
+                                     mode=cv2.STEREO_SGBM_MODE_HH if P == 8 else cv2.STEREO_SGBM_MODE_SGBM)
+        sgbm.compute(l, r)
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 5.0:
+            sgbm.compute(l, r); k += 1
+        out["opencv_sgbm_pairs_per_s"] = round(k / (time.perf_counter() - t0), 3)
+    except Exception:
+        pass
+    return out
 
 
 def main():
