@@ -83,6 +83,9 @@ class Engine:
         ch = 3 if (left.dim() >= 3 and left.shape[-1] == 3 and left.shape[-2] == self.width
                    and left.shape[-3] == self.height) else 1
         inner = 2 if ch == 3 else 1
+        for t in (left, right):
+            if tuple(t.shape[-inner - 1:][:2]) != (self.height, self.width):
+                raise EngineError(f"image shape {tuple(t.shape)} does not match the engine's {self.height}x{self.width} (bad step/size)")
         n, lp, ls, lfs = _geom(left, inner)
         n2, rp, rs, rfs = _geom(right, inner)
         if n != n2 or left.dtype != torch.uint8 or right.dtype != torch.uint8:

@@ -445,3 +445,67 @@ def test_temporal_vote(torch_cuda):
         got = eng.plane_temporal_vote(dev(torch, planes), [dev(torch, p) for p in prev], [dev(torch, f) for f in flows]).cpu().numpy()
         assert (got == O.temporal_vote(planes, prev, flows)).all(), n_prev
     eng.close()
+
+
+def test_engine_lifecycle_and_bad_arguments(torch_cuda):
+    """Create/destroy must not leak device memory; malformed pitches / pointers are refused with a message."""
+    torch = torch_cuda
+    from cartslam import EngineError
+    l = torch.zeros((96, 320), dtype=torch.uint8, device="cuda")
+
+    def cycle(n):
+        for _ in range(n):
+            eng = make_engine(320, 96, 128, 8, inflight=3)
+            eng.compute_disparity(l, l)
+            torch.cuda.synchronize()
+            eng.close()
+
+    cycle(2)  # first use loads code objects and grows the runtime's own pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(8)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 16 << 20, f"leak: {free0 - free1} bytes over 8 create/destroy cycles"
+    eng = make_engine(320, 96, 64, 4, inflight=2)
+    with pytest.raises(EngineError, match="does not match"):
+        eng.compute_disparity(l[:, :300], l[:, :300])              # image narrower than the engine's width
+    with pytest.raises(EngineError, match="contiguous"):
+        eng.compute_disparity(l, l, out=torch.zeros((96, 640), dtype=torch.int16, device="cuda")[:, ::2])  # non-contiguous rows
+    with pytest.raises(EngineError):
+        eng.compute_disparity(l.cpu(), l.cpu())                     # host tensors are not device memory
+    with pytest.raises(EngineError):
+        eng.interpolate(torch.zeros((96, 320), dtype=torch.int16, device="cuda"), 9, 1, 64, 320)  # radius > 8
+    eng.close()
+
+
+def test_concurrent_host_threads_one_engine(torch_cuda):
+    """The reference enters one module object for up to 12 frames at once (include/cartslam.hpp:4-5): 8 host threads,
+    each on its own stream, share one engine with 4 workspace slots; every result must be bit-exact."""
+    torch = torch_cuda
+    import threading
+    w, h, D, P = 256, 80, 64, 8
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=4)
+    pairs = [synth.make_pair(w, h, D, 4, seed=300 + i)[:2] for i in range(8)]
+    expected = [O.disparity_module(l, r, D, P, 4, radius=2, iterations=1) for l, r in pairs]
+    results, errors = [None] * 8, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    out = eng.compute_disparity(dev(torch, pairs[i][0]), dev(torch, pairs[i][1]))
+                s.synchronize()
+            results[i] = out.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(8):
+        assert (results[i] == expected[i]).all(), f"thread {i}"
+    eng.close()
