@@ -166,14 +166,53 @@ __device__ __forceinline__ uint32_t group_allsum(uint32_t v) {
     return v;
 }
 
+// wave-uniform values kept in SGPRs: per-lane addresses become "scalar base + 32-bit lane offset" (saddr form), and
+// the per-step pointer increments run on the scalar unit instead of 64-bit VALU adds
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ ptrdiff_t uniform(ptrdiff_t v) {  // element offsets from kernel-argument bases (pointer provenance kept)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (ptrdiff_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Pins a wave-uniform pointer into an SGPR pair so that "pointer + zero-extended 32-bit lane byte offset" selects the
+// scalar-base addressing form (global_load ... v_off, s[base:base+1]) instead of a 64-bit VALU add per access.  The
+// result is typed as a GLOBAL-address-space pointer: the asm hides the kernel-argument provenance the compiler would
+// otherwise use to pick global_* over flat_* instructions.
+#define CART_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ CART_GLOBAL T *sgpr(T *p) {
+    asm volatile("" : "+s"(p));
+    return (CART_GLOBAL T *)p;
+}
+// keeps the zero-extension of a lane offset next to its use: hoisted out of the loop as a 64-bit value it would no longer
+// match the scalar-base addressing pattern
+__device__ __forceinline__ unsigned pin_v(unsigned off) {
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *ubase, unsigned byte_off) {
+    return *(const CART_GLOBAL uint32_t *)((const CART_GLOBAL char *)sgpr(ubase) + pin_v(byte_off));
+}
+typedef uint32_t u32x4_g4 __attribute__((ext_vector_type(4), aligned(4)));
+// 16 consecutive features at a 4-byte aligned address (4 x dwordx4)
+__device__ __forceinline__ void ld_u32x16(const uint32_t *ubase, unsigned byte_off, uint32_t (&r)[16]) {
+    const CART_GLOBAL char *b = (const CART_GLOBAL char *)sgpr(ubase) + pin_v(byte_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x4_g4 v = *(const CART_GLOBAL u32x4_g4 *)(b + 16 * i);
+        r[4 * i + 0] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+    }
+}
+
 struct CensusRegs {
     uint32_t fl;
     uint32_t r[16];
 };
 
-__device__ __forceinline__ void load_census(const uint32_t *pl, const uint32_t *pr, CensusRegs &c) {
-    c.fl = *pl;
-    load_u32s<16>(pr, c.r);
+// left feature + the lane's 16 right features; pl / pr are wave-uniform, the offsets per lane (bytes)
+__device__ __forceinline__ void load_census(const uint32_t *pl, unsigned off_l, const uint32_t *pr, unsigned off_r, CensusRegs &c) {
+    c.fl = ld_u32(pl, off_l);
+    ld_u32x16(pr, off_r, c.r);
 }
 
 // x[k] = left feature ^ right feature k: consumes the loaded registers right away so that the next
@@ -185,7 +224,7 @@ __device__ __forceinline__ void agg_xor(const CensusRegs &c, uint32_t (&xr)[16])
 
 template <int LPP>
 __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&xr)[16], uint32_t sel_lo,
-                                         uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, uint8_t *po) {
+                                         uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, CART_GLOBAL uint8_t *po) {
     // matching cost minus the running minimum, packed like the state: cm[i] = (C[d0+i]-m, C[d0+i+8]-m)
     uint32_t negm = 0u - (mm & 0xffffu);
     asm volatile("" : "+v"(negm));  // keep "+ (-m)" an add so it folds into v_bcnt_u32_b32's accumulate operand
@@ -222,7 +261,7 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
     {   // write-once streaming data: non-temporal so the slabs do not evict the census planes from L2
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         const v4u q = {o.x, o.y, o.z, o.w};
-        __builtin_nontemporal_store(q, reinterpret_cast<v4u *>(po));
+        __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);
     }
 #endif
     // min over the pixel's D disparities, replicated into both halves
@@ -279,7 +318,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     const int frame = rb / nblk;
     const int b = rb - frame * nblk + a.dirs[di].blk0;
     const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP;  // lane inside the pixel's lane group, pixel group inside the wave
     const int line0 = (b - a.dirs[di].blk0) * LINES_PER_BLOCK + wid * P;  // wave-uniform
     const int line = line0 + pg;
@@ -290,9 +329,6 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     // selectors of the two stitching v_perm: 0x0d bytes inject 0xFFFF where d-1 / d+1 leave [0, D)
     const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
     const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
-    const uint32_t *cen_l = a.cen_l + (size_t)frame * g.census_elems;
-    const uint32_t *cen_r = a.cen_r + (size_t)frame * g.census_elems;
-    uint8_t *slab = a.slabs + (size_t)(frame * g.P + a.dirs[di].path) * g.slab_bytes;
 
     uint32_t st[8];
 #pragma unroll
@@ -310,34 +346,39 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
         // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
         __builtin_amdgcn_s_setprio(3);
         if (line >= nlines) return;
-        const int y = a.dirs[di].jmin + line;
+        const int y0r = a.dirs[di].jmin + line0;          // row of the wave's first line (uniform)
         const int x = dx > 0 ? 0 : g.w - 1, t1 = g.w;
-        const uint32_t *pl = cen_l + (size_t)y * g.cpitch + g.cpadl + x;
-        const uint32_t *pr = cen_r + (size_t)y * g.cpitch + g.cpadl + x - g.min_disp - d0 - 15;
-        uint8_t *po = slab + ((size_t)y * g.w + x) * g.D + d0;
+        // uniform bases + non-negative per-lane element offsets
+        const uint32_t *pl_u = a.cen_l + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x);
+        const uint32_t *pr_u = a.cen_r + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x - g.min_disp - (WN::D - 1));
+        uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0r * g.w + x) * g.D);
+        const unsigned lo_l = (unsigned)pg * g.cpitch * 4u, lo_r = lo_l + (unsigned)(WN::D - 16 - d0) * 4u;  // bytes
+        const unsigned lo_o = (unsigned)pg * g.w * g.D + d0;
         const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
+        const uint32_t *pl = pl_u, *pr = pr_u;
+        uint8_t *po = po_u;
         uint32_t xr[16];
-        load_census(pl, pr, ca);
-        load_census(pl + cstride, pr + cstride, cb);
+        load_census(pl, lo_l, pr, lo_r, ca);
+        load_census(pl + cstride, lo_l, pr + cstride, lo_r, cb);
         int t = 0;
         for (; t + 1 < t1; t += 2) {
             agg_xor(ca, xr);
             __builtin_amdgcn_sched_barrier(0);
-            load_census(pl + 2 * cstride, pr + 2 * cstride, ca);  // step t+2 (reads row padding past the end)
+            load_census(pl + 2 * cstride, lo_l, pr + 2 * cstride, lo_r, ca);  // step t+2 (reads row padding past the end)
             __builtin_amdgcn_sched_barrier(0);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
             agg_xor(cb, xr);
             __builtin_amdgcn_sched_barrier(0);
-            load_census(pl + 3 * cstride, pr + 3 * cstride, cb);  // step t+3
+            load_census(pl + 3 * cstride, lo_l, pr + 3 * cstride, lo_r, cb);  // step t+3
             __builtin_amdgcn_sched_barrier(0);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po + ostride);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + ostride) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
             pl += 2 * cstride; pr += 2 * cstride; po += 2 * ostride;
         }
         if (t < t1) {
             agg_xor(ca, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
         }
         return;
     }
@@ -363,11 +404,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     if (nv < P || tm0 >= tm1) { tm0 = te; tm1 = te; }  // everything through the ragged path
 
     // cooperative window load: LDS slot l = 64*i + lane  <-  window dword 16*(l/20) + min(l%20, 15)
-    int goff[WN::NLD];
+    unsigned goff[WN::NLD];
 #pragma unroll
     for (int i = 0; i < WN::NLD; ++i) {
         const int l = 64 * i + lane;
-        goff[i] = 16 * (l / 20) + min(l % 20, 15);
+        goff[i] = (unsigned)(16 * (l / 20) + min(l % 20, 15)) * 4u;  // bytes
     }
     // this lane's 16 features: window dwords wl .. wl+15, wl = pg + D-16 - 16*gl
     const int wl = pg + WN::D - 16 - d0;
@@ -380,58 +421,61 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     // pointers as a function of the step t
     const ptrdiff_t cstride = (ptrdiff_t)dy * g.cpitch + dx;
     const ptrdiff_t ostride = ((ptrdiff_t)dy * g.w + dx) * g.D;
-    const uint32_t *pw_base = cen_r + (ptrdiff_t)ys * g.cpitch + g.cpadl + jf - g.min_disp - (WN::D - 1);  // window start at t = 0
-    const uint32_t *pl_base = cen_l + (ptrdiff_t)ys * g.cpitch + g.cpadl + j;
-    uint8_t *po_base = slab + ((ptrdiff_t)ys * g.w + j) * g.D + d0;
+    // uniform bases (line jf = first line of the wave) + per-lane offsets (pg = this lane's line inside the wave)
+    const ptrdiff_t cen_off = (ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)ys * g.cpitch + g.cpadl + jf;
+    const uint32_t *pw_base = a.cen_r + uniform(cen_off - g.min_disp - (WN::D - 1));  // window start at t = 0
+    const uint32_t *pl_u = a.cen_l + uniform(cen_off);
+    uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + jf) * g.D);
+    const unsigned lo_l = (unsigned)pg * 4u, lo_o = (unsigned)(pg * WN::D + d0);  // bytes
 
     // ragged start / end of diagonal lines (and waves with invalid lines): simple, fully synchronous steps
     auto ragged = [&](int ta, int tz) {
         for (int t = ta; t < tz; ++t) {
             const uint32_t *pw = pw_base + t * cstride;
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
+            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = ld_u32(pw, goff[i]);
             if (t >= t0 && t < t1) {
                 uint32_t xr[16];
-                ca.fl = pl_base[t * cstride];
+                ca.fl = ld_u32(pl_u + t * cstride, lo_l);
                 win_read<LPP>(buf0, base_slot, xslot, ca.r);
                 agg_xor(ca, xr);
-                agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po_base + t * ostride);
+                agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po_u + t * ostride) + pin_v(lo_o));
             }
         }
     };
     ragged(tb, tm0);
     if (tm0 < tm1) {
-        const uint32_t *pw = pw_base + tm0 * cstride, *pl = pl_base + tm0 * cstride;
-        uint8_t *po = po_base + tm0 * ostride;
+        const uint32_t *pw = pw_base + tm0 * cstride, *pl = pl_u + tm0 * cstride;
+        uint8_t *po = po_u + tm0 * ostride;
         uint32_t g0[WN::NLD], g1[WN::NLD], f0, f1;
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = pw[goff[i]];
-        f0 = *pl;
+        for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = ld_u32(pw, goff[i]);
+        f0 = ld_u32(pl, lo_l);
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) g1[i] = pw[cstride + goff[i]];  // step tm0+1
-        f1 = pl[cstride];
+        for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + cstride, goff[i]);  // step tm0+1
+        f1 = ld_u32(pl + cstride, lo_l);
         uint32_t xr[16];
         int t = tm0;
         for (; t + 1 < tm1; t += 2) {
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) g0[i] = pw[2 * cstride + goff[i]];  // step t+2, issued before this step's store
+            for (int i = 0; i < WN::NLD; ++i) g0[i] = ld_u32(pw + 2 * cstride, goff[i]);  // step t+2, issued before this step's store
             ca.fl = f0;
-            f0 = pl[2 * cstride];
+            f0 = ld_u32(pl + 2 * cstride, lo_l);
             __builtin_amdgcn_sched_barrier(0);
             win_read<LPP>(buf0, base_slot, xslot, ca.r);
             agg_xor(ca, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = g1[i];        // window of step t+1
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) g1[i] = pw[3 * cstride + goff[i]];  // step t+3
+            for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + 3 * cstride, goff[i]);  // step t+3
             cb.fl = f1;
-            f1 = pl[3 * cstride];
+            f1 = ld_u32(pl + 3 * cstride, lo_l);
             __builtin_amdgcn_sched_barrier(0);
             win_read<LPP>(buf1, base_slot, xslot, cb.r);
             agg_xor(cb, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po + ostride);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + ostride) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = g0[i];        // window of step t+2
@@ -441,7 +485,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
             ca.fl = f0;
             win_read<LPP>(buf0, base_slot, xslot, ca.r);
             agg_xor(ca, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, po);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
         }
     }
     ragged(tm1, te);
