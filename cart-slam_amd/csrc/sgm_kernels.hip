@@ -186,16 +186,16 @@ __device__ __forceinline__ CART_GLOBAL T *sgpr(T *p) {
 }
 // keeps the zero-extension of a lane offset next to its use: hoisted out of the loop as a 64-bit value it would no longer
 // match the scalar-base addressing pattern
-__device__ __forceinline__ unsigned pin_v(unsigned off) {
+__device__ __forceinline__ unsigned pin_v(unsigned &off) {  // in place: no register copy
     asm volatile("" : "+v"(off));
     return off;
 }
-__device__ __forceinline__ uint32_t ld_u32(const uint32_t *ubase, unsigned byte_off) {
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *ubase, unsigned &byte_off) {
     return *(const CART_GLOBAL uint32_t *)((const CART_GLOBAL char *)sgpr(ubase) + pin_v(byte_off));
 }
 typedef uint32_t u32x4_g4 __attribute__((ext_vector_type(4), aligned(4)));
 // 16 consecutive features at a 4-byte aligned address (4 x dwordx4)
-__device__ __forceinline__ void ld_u32x16(const uint32_t *ubase, unsigned byte_off, uint32_t (&r)[16]) {
+__device__ __forceinline__ void ld_u32x16(const uint32_t *ubase, unsigned &byte_off, uint32_t (&r)[16]) {
     const CART_GLOBAL char *b = (const CART_GLOBAL char *)sgpr(ubase) + pin_v(byte_off);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -210,7 +210,7 @@ struct CensusRegs {
 };
 
 // left feature + the lane's 16 right features; pl / pr are wave-uniform, the offsets per lane (bytes)
-__device__ __forceinline__ void load_census(const uint32_t *pl, unsigned off_l, const uint32_t *pr, unsigned off_r, CensusRegs &c) {
+__device__ __forceinline__ void load_census(const uint32_t *pl, unsigned &off_l, const uint32_t *pr, unsigned &off_r, CensusRegs &c) {
     c.fl = ld_u32(pl, off_l);
     ld_u32x16(pr, off_r, c.r);
 }
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
         const uint32_t *pl_u = a.cen_l + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x);
         const uint32_t *pr_u = a.cen_r + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x - g.min_disp - (WN::D - 1));
         uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0r * g.w + x) * g.D);
-        const unsigned lo_l = (unsigned)pg * g.cpitch * 4u, lo_r = lo_l + (unsigned)(WN::D - 16 - d0) * 4u;  // bytes
-        const unsigned lo_o = (unsigned)pg * g.w * g.D + d0;
+        unsigned lo_l = (unsigned)pg * g.cpitch * 4u, lo_r = lo_l + (unsigned)(WN::D - 16 - d0) * 4u;  // bytes
+        unsigned lo_o = (unsigned)pg * g.w * g.D + d0;
         const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
         const uint32_t *pl = pl_u, *pr = pr_u;
         uint8_t *po = po_u;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
     const uint32_t *pw_base = a.cen_r + uniform(cen_off - g.min_disp - (WN::D - 1));  // window start at t = 0
     const uint32_t *pl_u = a.cen_l + uniform(cen_off);
     uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + jf) * g.D);
-    const unsigned lo_l = (unsigned)pg * 4u, lo_o = (unsigned)(pg * WN::D + d0);  // bytes
+    unsigned lo_l = (unsigned)pg * 4u, lo_o = (unsigned)(pg * WN::D + d0);  // bytes
 
     // ragged start / end of diagonal lines (and waves with invalid lines): simple, fully synchronous steps
     auto ragged = [&](int ta, int tz) {
