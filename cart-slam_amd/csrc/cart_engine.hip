@@ -711,7 +711,11 @@ int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, si
     } else if (what >= CART_DBG_PATH0 && what < CART_DBG_PATH0 + g.P) {
         src = e->slabs + ((size_t)slot * g.P + (what - CART_DBG_PATH0)) * g.slab_bytes; need = g.slab_bytes;
         if (bytes < need) return fail("buffer too small");
-        HIP_TRY(hipMemcpy(host_dst, src, need, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> raw(need);
+        HIP_TRY(hipMemcpy(raw.data(), src, need, hipMemcpyDeviceToHost));
+        uint8_t *d = static_cast<uint8_t *>(host_dst);  // undo the in-slab chunk order -> plain [h][w][D]
+        for (size_t c = 0; c < need; c += 16)
+            for (int k = 0; k < 16; ++k) d[c + kSlabChunkOrder[k]] = raw[c + k];
     } else if (what == CART_DBG_WTA_L) {
         src = e->wta_l + (size_t)slot * g.npx; need = g.npx * 2;
         if (bytes < need) return fail("buffer too small");

@@ -13,6 +13,9 @@ constexpr int kMaxPaths = 8;
 constexpr int kWtaTileX = 64;        // pixels of one row handled by one WTA block
 constexpr int kMaxBatchArgs = 128;   // frames per classify launch (params travel as kernel args)
 constexpr uint32_t kWtaInvalid = 0xFFFFu;
+// Byte order of the 16 disparities of one lane chunk inside a cost slab: byte k of the chunk holds disparity
+// chunk_base + kSlabChunkOrder[k] (the aggregation kernel's split-halves register order; the WTA consumes it as is).
+constexpr int kSlabChunkOrder[16] = {0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15};
 
 // Geometry of one engine instance; all buffers below are per workspace slot (= frame).
 struct Geometry {

@@ -248,12 +248,12 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         t = pk_min(pk_min(t, a[i]), mp2);
         n[i] = pk_add(t, cm[i]);  // oracle S4, both halves at once
     }
-    // u8 slab bytes in disparity order d0 .. d0+15
-    const uint32_t q01 = perm(n[1], n[0], 0x06020400u), q23 = perm(n[3], n[2], 0x06020400u);
-    const uint32_t q45 = perm(n[5], n[4], 0x06020400u), q67 = perm(n[7], n[6], 0x06020400u);
+    // u8 slab bytes of the lane's 16 disparities in the kernel's native order (one v_perm per register pair): dword q
+    // holds d0 + {2q, 2q+8, 2q+1, 2q+9}; the WTA widens byte pairs straight back into the same split-halves registers
+    // (slab byte layout: see kSlabChunkOrder in engine_internal.h)
     uint4 o;
-    o.x = perm(q23, q01, 0x05040100u); o.y = perm(q67, q45, 0x05040100u);
-    o.z = perm(q23, q01, 0x07060302u); o.w = perm(q67, q45, 0x07060302u);
+    o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
+    o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
 #ifdef CART_ABLATE_STORE  // timing experiment only: keep the bytes live, skip the slab store
     asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
     (void)po;
@@ -506,8 +506,10 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
 
 // ------------------------------------------------------------------ winner takes all
 // Block = 64 pixels of one row; a pixel is owned by LPP = D/16 lanes, 16 disparities per lane as 8
-// packed u16 pairs s[k] = (S[d0+2k], S[d0+2k+1]).  Per path one 16-byte non-temporal load per lane, the
+// packed u16 pairs.  Per path one 16-byte non-temporal load per lane, the
 // bytes are widened by v_perm_b32 and summed with v_pk_add_u16 (1 VALU op per cell and path).
+//   * the slab bytes of a lane's 16 disparities arrive in the aggregation kernel's split-halves order, so byte pairs
+//     widen directly into registers sm[k] = (S[d0+k], S[d0+k+8]);
 //   * argmin (ties -> lowest d, oracle S5): packed keys S*16 + local index, packed min tree, then one
 //     32-bit key (S<<16 | d) per lane reduced over the pixel's lanes by DPP;
 //   * uniqueness: (float)S*u >= (float)best is monotone in S, so it equals S >= T for the integer
@@ -565,14 +567,15 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
                 sm[2 * q + 1] = pk_add(sm[2 * q + 1], perm(0u, v[q], 0x0c030c02u));
             }
         }
+        // LDS tile in natural disparity order: (S[d0+2k], S[d0+2k+1]) = low / high halves of sm[2k], sm[2k+1]
         v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * D + d0);
-        dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
-        dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
-        // packed argmin keys: S*16 + (2k | 2k+1)
+        dst[0] = v4u{perm(sm[1], sm[0], 0x05040100u), perm(sm[3], sm[2], 0x05040100u), perm(sm[5], sm[4], 0x05040100u), perm(sm[7], sm[6], 0x05040100u)};
+        dst[1] = v4u{perm(sm[1], sm[0], 0x07060302u), perm(sm[3], sm[2], 0x07060302u), perm(sm[5], sm[4], 0x07060302u), perm(sm[7], sm[6], 0x07060302u)};
+        // packed argmin keys: S*16 + local disparity index (k | k+8)
         uint32_t key[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
+            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)k, (uint16_t)(k + 8)};
             key[k] = __builtin_bit_cast(uint32_t, kk);
         }
         uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
