@@ -225,17 +225,9 @@ __device__ __forceinline__ void agg_xor(const CensusRegs &c, uint32_t (&xr)[16])
 template <int LPP>
 __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&xr)[16], uint32_t sel_lo,
                                          uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, CART_GLOBAL uint8_t *po) {
-    // matching cost minus the running minimum, packed like the state: cm[i] = (C[d0+i]-m, C[d0+i+8]-m)
-    uint32_t negm = 0u - (mm & 0xffffu);
-    asm volatile("" : "+v"(negm));  // keep "+ (-m)" an add so it folds into v_bcnt_u32_b32's accumulate operand
-    uint32_t cm[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t clo = (uint32_t)__builtin_popcount(xr[15 - i]) + negm;
-        const uint32_t chi = (uint32_t)__builtin_popcount(xr[7 - i]) + negm;
-        cm[i] = perm(chi, clo, 0x05040100u);
-    }
-    const uint32_t mp2 = mm + p2p2;  // halves stay < 2^15: a plain 32-bit add (2.7 clk) equals the packed one (4.5 clk)
+    // Issue cost on gfx950 (profiles/tools/valu_rate.hip): v_add/v_sub/v_xor ~2.7 clk, packed ops / v_perm / v_bcnt /
+    // shifts ~4.5 clk.  Wherever a packed op cannot carry or borrow between the halves, the plain 32-bit one is used.
+    const uint32_t mp2 = mm + p2p2;  // halves stay < 2^15
     // neighbour vectors at the two ends: (prev lane's L[d0-1], own L[d0+7]) and (own L[d0+8], next lane's L[d0+16])
     const uint32_t lo0 = perm(a[7], dpp_mov<DPP_ROW_SHR1>(a[7]), sel_lo);
     const uint32_t hi7 = perm(dpp_mov<DPP_ROW_SHL1>(a[0]), a[0], sel_hi);
@@ -246,7 +238,13 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         const uint32_t hi = i == 7 ? hi7 : a[i + 1];
         uint32_t t = pk_min(lo, hi) + p1p1;  // no carry between halves (min(lo,hi) is a real cost < 2^15)
         t = pk_min(pk_min(t, a[i]), mp2);
-        n[i] = pk_add(t, cm[i]);  // oracle S4, both halves at once
+        // oracle S4: L = C + (min(...) - m).  Every candidate of the min is >= m in both halves, so "- m" is a plain
+        // 32-bit subtract; the low-half cost rides on v_bcnt's accumulate operand, the high-half one is shifted in.
+        uint32_t u = t - mm;
+        asm volatile("" : "+v"(u));  // keep the three adds apart: v_sub (fast), v_bcnt with accumulate, v_lshl_add
+        uint32_t lo_sum = (uint32_t)__builtin_popcount(xr[15 - i]) + u;
+        asm volatile("" : "+v"(lo_sum));
+        n[i] = ((uint32_t)__builtin_popcount(xr[7 - i]) << 16) + lo_sum;
     }
     // u8 slab bytes of the lane's 16 disparities in the kernel's native order (one v_perm per register pair): dword q
     // holds d0 + {2q, 2q+8, 2q+1, 2q+9}; the WTA widens byte pairs straight back into the same split-halves registers

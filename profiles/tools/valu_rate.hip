@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
             if (OP == 15) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(x) : "v"(b));
             if (OP == 16) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
             if (OP == 17) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 18) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 19) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 20) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 21) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 22) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 23) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 24) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 25) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x));
+            if (OP == 26) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 27) asm volatile("v_min_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 28) asm volatile("v_max_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 29) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 30) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 31) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b));
+            if (OP == 32) asm volatile("v_pk_add_u16 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(x) : "v"(b));
+            if (OP == 33) asm volatile("v_min_i32 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 34) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 35) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(b));
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -65,12 +83,17 @@ void run(const char *name, uint32_t *d, int waves_per_simd) {
 int main() {
     uint32_t *d;
     hipMalloc(&d, 256 * 8 * 256 * 4);
-    for (int w : {1, 4}) {
+    for (int w : {4}) {
         run<0>("v_min_u32", d, w); run<1>("v_pk_min_u16", d, w); run<2>("v_pk_add_u16", d, w); run<3>("v_perm_b32", d, w);
         run<4>("v_bcnt_u32_b32", d, w); run<5>("v_xor_b32", d, w); run<6>("v_min3_u32", d, w); run<7>("v_add_u32", d, w);
         run<8>("v_alignbit_b32", d, w); run<9>("v_min_u32_dpp", d, w); run<10>("v_pk_sub_u16 clamp", d, w);
         run<11>("v_pk_mad_u16", d, w); run<12>("v_lshl_or_b32", d, w); run<13>("v_pk_fma_f32", d, w); run<14>("v_fma_f32", d, w);
         run<15>("v_add_u32_sdwa", d, w); run<16>("v_sad_u8", d, w); run<17>("v_dot4_u32_u8", d, w);
+        run<18>("v_pk_min_f16", d, w); run<19>("v_pk_min_i16", d, w); run<20>("v_pk_add_f16", d, w); run<21>("v_sub_u32", d, w);
+        run<22>("v_and_b32", d, w); run<23>("v_or_b32", d, w); run<24>("v_mov_b32", d, w); run<25>("v_lshlrev_b32", d, w);
+        run<26>("v_min_f32", d, w); run<27>("v_min_u16", d, w); run<28>("v_max_u32", d, w); run<29>("v_add3_u32", d, w);
+        run<30>("v_and_or_b32", d, w); run<31>("v_cndmask_b32", d, w); run<32>("v_pk_add_u16 opsel", d, w); run<33>("v_min_i32", d, w);
+        run<34>("v_xad_u32", d, w); run<35>("v_pk_mul_lo_u16", d, w);
     }
     return 0;
 }
