@@ -299,8 +299,9 @@ __device__ __forceinline__ void win_read(const uint32_t *lds_buf, int base_slot,
     }
 }
 
+// 6 waves per SIMD (<= 80 VGPRs) fit without spills for D >= 128; the D = 64 variant carries 15 lane offsets more
 template <int LPP>
-__global__ __launch_bounds__(256) void aggregate_kernel(AggArgs a) {
+__global__ __launch_bounds__(256, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
     using WN = Win<LPP>;
     constexpr int P = WN::P;
     constexpr int LINES_PER_BLOCK = 4 * P;
