@@ -507,8 +507,8 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
 // Block = 64 pixels of one row; a pixel is owned by LPP = D/16 lanes, 16 disparities per lane as 8
 // packed u16 pairs.  Per path one 16-byte non-temporal load per lane, the
 // bytes are widened by v_perm_b32 and summed with v_pk_add_u16 (1 VALU op per cell and path).
-//   * the slab bytes of a lane's 16 disparities arrive in the aggregation kernel's split-halves order, so byte pairs
-//     widen directly into registers sm[k] = (S[d0+k], S[d0+k+8]);
+//   * the slab bytes of a lane's 16 disparities arrive in the aggregation kernel's split-halves order, whose even /
+//     odd bytes are natural adjacent disparity pairs: one v_and or v_perm plus a plain add per two cells;
 //   * argmin (ties -> lowest d, oracle S5): packed keys S*16 + local index, packed min tree, then one
 //     32-bit key (S<<16 | d) per lane reduced over the pixel's lanes by DPP;
 //   * uniqueness: (float)S*u >= (float)best is monotone in S, so it equals S >= T for the integer
@@ -554,6 +554,9 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
     for (int pass = 0; pass < NPASS; ++pass) {
         const int xl = pass * PPP + grp;
         const int xc = min(x0 + xl, g.w - 1);
+        // Slab chunk order {0,8,1,9,...}: the even bytes of dword q are disparities (2q, 2q+1), the odd bytes (2q+8, 2q+9).
+        // sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q]): natural adjacent pairs.  Even bytes need one
+        // v_and, odd bytes one v_perm; the accumulation is a plain 32-bit add (sums stay < 2^16 per half).
         uint32_t sm[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) sm[k] = 0;
@@ -562,19 +565,18 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
             const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)r * g.slab_bytes));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                sm[2 * q] = pk_add(sm[2 * q], perm(0u, v[q], 0x0c010c00u));
-                sm[2 * q + 1] = pk_add(sm[2 * q + 1], perm(0u, v[q], 0x0c030c02u));
+                sm[q] += v[q] & 0x00ff00ffu;
+                sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
             }
         }
-        // LDS tile in natural disparity order: (S[d0+2k], S[d0+2k+1]) = low / high halves of sm[2k], sm[2k+1]
-        v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * D + d0);
-        dst[0] = v4u{perm(sm[1], sm[0], 0x05040100u), perm(sm[3], sm[2], 0x05040100u), perm(sm[5], sm[4], 0x05040100u), perm(sm[7], sm[6], 0x05040100u)};
-        dst[1] = v4u{perm(sm[1], sm[0], 0x07060302u), perm(sm[3], sm[2], 0x07060302u), perm(sm[5], sm[4], 0x07060302u), perm(sm[7], sm[6], 0x07060302u)};
-        // packed argmin keys: S*16 + local disparity index (k | k+8)
+        v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * D + d0);  // LDS tile in natural disparity order
+        dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
+        dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
+        // packed argmin keys: S*16 + local disparity index
         uint32_t key[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)k, (uint16_t)(k + 8)};
+            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
             key[k] = __builtin_bit_cast(uint32_t, kk);
         }
         uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
