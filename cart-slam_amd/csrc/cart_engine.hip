@@ -33,7 +33,8 @@ int fail(const std::string &msg) {
 
 struct Slot {
     bool busy = false;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;          // recorded only on the FIRST slot of a lease ...
+    int owner = -1;                     // ... every slot of the lease points at that slot
     hipStream_t last_stream = nullptr;
     bool used = false;
 };
@@ -100,11 +101,16 @@ int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
     }
     for (int k = 0; k < n; ++k) e->slots[s0 + k].busy = true;
     lk.unlock();
+    // Cross-stream reuse of a slot waits for the event of the lease that used it last.  That event may have been
+    // re-recorded by a later lease of its owner slot: waiting for more than necessary is harmless (an event wait only
+    // ever refers to work enqueued before the wait).
+    int waited = -1;
     for (int k = 0; k < n; ++k) {
         Slot &s = e->slots[s0 + k];
-        if (s.used && s.last_stream != stream) {
-            hipError_t err = hipStreamWaitEvent(stream, s.done, 0);
+        if (s.used && s.last_stream != stream && s.owner != waited) {
+            hipError_t err = hipStreamWaitEvent(stream, e->slots[s.owner].done, 0);
             if (err != hipSuccess) return fail(std::string("hipStreamWaitEvent: ") + hipGetErrorString(err));
+            waited = s.owner;
         }
     }
     out->e = e; out->s0 = s0; out->n = n; out->stream = stream;
@@ -113,9 +119,10 @@ int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
 
 void release(const Lease &l) {
     cart_engine *e = l.e;
+    (void)hipEventRecord(e->slots[l.s0].done, l.stream);  // ONE in-queue marker per lease (16 of them cost ~80 us of GPU idle)
     for (int k = 0; k < l.n; ++k) {
         Slot &s = e->slots[l.s0 + k];
-        (void)hipEventRecord(s.done, l.stream);
+        s.owner = l.s0;
         s.last_stream = l.stream;
         s.used = true;
     }
