@@ -51,7 +51,10 @@ std::future<void> System::run() {
     {
         std::unique_lock<std::mutex> lock(runMutex);
         runCondition.wait(lock, [this] { return activeRuns < concurrentRunLimit; });  // cartslam.cpp:196-198
+        auto sourceTiming = timing::initTiming("DataSource", runId + 1);
+        timing::startTiming(sourceTiming);
         auto element = dataSource->getNext();
+        timing::endTiming(sourceTiming);
         run = std::make_shared<SystemRunData>(++runId, this, element);
         runs.push_back(run);
         if (runs.size() > runRetention) runs.erase(runs.begin());  // cartslam.cpp:202-205

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "cartslam_amd/modules/depth.hpp"
 #include "cartslam_amd/modules/disparity.hpp"
@@ -14,10 +15,31 @@ void hipCheck(hipError_t e, const char *what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-struct ScopedStream {  // the reference creates one stream per invocation (disparity.cu:56, planeseg.cu:279-280)
+// The reference creates and destroys one stream per invocation (disparity.cu:56, planeseg.cu:279-280,300-301); stream
+// creation costs ~100 us here, so invocations borrow a stream from a pool instead (same concurrency, no churn).
+class StreamPool {
+   public:
+    static StreamPool &instance() { static StreamPool p; return p; }
+    hipStream_t acquire() {
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            if (!idle.empty()) { hipStream_t s = idle.back(); idle.pop_back(); return s; }
+        }
+        hipStream_t s = nullptr;
+        hipCheck(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        return s;
+    }
+    void release(hipStream_t s) { std::lock_guard<std::mutex> lock(mutex); idle.push_back(s); }
+
+   private:
+    std::mutex mutex;
+    std::vector<hipStream_t> idle;
+};
+
+struct ScopedStream {
     hipStream_t s = nullptr;
-    ScopedStream() { hipCheck(hipStreamCreate(&s), "hipStreamCreate"); }
-    ~ScopedStream() { if (s) (void)hipStreamDestroy(s); }
+    ScopedStream() : s(StreamPool::instance().acquire()) {}
+    ~ScopedStream() { if (s) StreamPool::instance().release(s); }
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 

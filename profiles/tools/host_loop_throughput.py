@@ -1,0 +1,42 @@
+"""Throughput of the C++ frame loop (cart_slam_amd, per-frame module calls, <= 12 frames in flight) at 1242x375.
+Writes a 240-frame PGM sequence to /tmp, runs the reference-style config, reads the timing CSV."""
+import json, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "cart-slam_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+from cartslam import synth
+tmp = tempfile.mkdtemp(dir="/tmp")
+d = os.path.join(tmp, "ds", "sequences", "00"); os.makedirs(d + "/image_2"); os.makedirs(d + "/image_3")
+n = 240
+base = [synth.make_pair(1242, 375, 128, 4, frame=f) for f in range(4)]
+for f in range(n):
+    l, r, _ = base[f % 4]
+    for cam, img in ((2, l), (3, r)):
+        with open(f"{d}/image_{cam}/{f:06d}.pgm", "wb") as fh:
+            fh.write(b"P5\n1242 375\n255\n"); fh.write(img.tobytes())
+json.dump({"type": "kitti", "path": os.path.join(tmp, "ds"), "sequence": 0}, open(tmp + "/src.json", "w"))
+for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "num_disparities": 128, "paths": 8, "smoothing_radius": 2, "smoothing_iterations": 1},
+                                                        {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
+                   ("reference default (D=256, 4 paths) + planeseg", [{"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1},
+                                                                      {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}])):
+    json.dump(mods, open(tmp + "/mod.json", "w"))
+    exe = os.path.join(ROOT, "cart-slam_amd", "build", "cart_slam_amd")
+    t0 = time.time()
+    r = subprocess.run([exe, tmp + "/src.json", tmp + "/mod.json", "--timing", tmp + "/t.csv"], capture_output=True, text=True)
+    wall = time.time() - t0
+    rows = [ln.strip().split(";") for ln in open(tmp + "/t.csv")][1:]
+    fr = [x for x in rows if x[0] == "Frame"]
+    span_ms = max(int(x[4]) for x in fr) - min(int(x[2]) for x in fr)
+    disp = [int(x[6]) for x in rows if x[0] == "ImageDisparity"]
+    print(f"{name}: {r.stdout.strip()} | {len(fr)} frames in {span_ms} ms -> {len(fr) / max(span_ms, 1) * 1e3:.0f} pairs/s; "
+          f"median ImageDisparity module time {sorted(disp)[len(disp) // 2]} us; process wall {wall:.2f} s")
+    ends = sorted(int(x[4]) for x in fr)
+    if len(ends) > 96:
+        print(f"   steady state (frames 48..{len(ends)}): {(len(ends) - 48) / max(ends[-1] - ends[47], 1) * 1e3:.0f} pairs/s")
+    fr.sort(key=lambda x: int(x[1]))
+    inits = [int(x[2]) for x in fr]
+    print("   frame init spacing ms:", [b - a for a, b in zip(inits[:16], inits[1:17])], " frame durations us:", [int(x[6]) for x in fr[:12]])
+    ps = [int(x[6]) for x in rows if x[0] == "PlaneSegmentation"]
+    print("   median PlaneSegmentation us:", sorted(ps)[len(ps) // 2])
+    ds = [int(x[6]) for x in rows if x[0] == "DataSource"]
+    print("   median DataSource (read + decode + upload) us:", sorted(ds)[len(ds) // 2])
