@@ -27,6 +27,13 @@ class PlaneParams(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class SuperpixelParams(C.Structure):
+    # mirrors cart_superpixel_params (include/cart_engine.h; reference cartconfig.cpp:121-133)
+    _fields_ = [(n, C.c_double) for n in (
+        "direct_clique_cost", "diagonal_clique_cost", "compactness_weight", "progressive_compactness_cost",
+        "image_weight", "disparity_weight")]
+
+
 # every symbol include/cart_engine.h declares, with its prototype
 _vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
 PROTOTYPES = {
@@ -48,6 +55,15 @@ PROTOTYPES = {
     "cart_plane_classify_dev": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _i, _vp, _sz, _sz, _vp]),
     "cart_plane_temporal_vote": (_i, [_vp, _vp, _sz, _i, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "cart_reproject_depth": (_i, [_vp, _i, _vp, _sz, _sz, C.POINTER(C.c_float), _vp, _sz, _sz, _vp]),
+    "cart_superpixel_default_params": (None, [C.POINTER(SuperpixelParams)]),
+    "cart_superpixels_create": (_i, [_vp, C.POINTER(SuperpixelParams), _i, _i, C.POINTER(_vp)]),
+    "cart_superpixels_destroy": (None, [_vp]),
+    "cart_superpixels_reset": (_i, [_vp, _vp]),
+    "cart_superpixels_set_labels": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "cart_superpixels_relax": (_i, [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp, _sz, _vp]),
+    "cart_superpixels_max_label": (_i, [_vp]),
+    "cart_superpixel_plane_classify": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.POINTER(PlaneParams), _i, C.POINTER(_vp), C.POINTER(_sz),
+                                           C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp, _sz, _vp]),
     "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),

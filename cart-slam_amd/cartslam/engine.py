@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EngineParams, PlaneParams
+from ._lib import EngineParams, PlaneParams, SuperpixelParams
 
 INVALID = -32768  # CARTSLAM_DISPARITY_INVALID, reference include/modules/disparity.hpp:17
 
@@ -176,6 +176,32 @@ class Engine:
         self._check(self._lib.cart_plane_temporal_vote(self._h, p, s, n, P, PS, F, FS, op, os_, _stream_ptr()), "cart_plane_temporal_vote")
         return out
 
+    # ---- superpixel plane labelling (reference src/modules/planeseg/sp_planeseg.cu:27-178) ----
+    def superpixel_plane_classify(self, deriv2, labels, max_label, params, prev_planes=(), flows=()):
+        """deriv2: int16 [h,w,2]; labels: uint16 [h,w] (torch has no uint16 arithmetic: pass an int16 view);
+        -> (planes_unsmoothed, planes) uint8 [h,w]."""
+        import torch
+        n = len(prev_planes)
+        if len(flows) != n:
+            raise EngineError("one flow per previous plane image")
+        _, dp, ds, _ = _geom(deriv2, 2)
+        _, lp, ls, _ = _geom(labels, 1)
+        if labels.element_size() != 2:
+            raise EngineError("labels must be a 16-bit tensor")
+        pp = params if isinstance(params, PlaneParams) else PlaneParams(*params)
+        uns = torch.empty(labels.shape, dtype=torch.uint8, device=labels.device)
+        out = torch.empty_like(uns)
+        _, up, us, _ = _geom(uns, 1)
+        _, op, os_, _ = _geom(out, 1)
+        P = (C.c_void_p * max(n, 1))(); PS = (C.c_size_t * max(n, 1))(); F = (C.c_void_p * max(n, 1))(); FS = (C.c_size_t * max(n, 1))()
+        for k in range(n):
+            _, q, qs, _ = _geom(prev_planes[k], 1)
+            _, fp, fs, _ = _geom(flows[k], 2)
+            P[k], PS[k], F[k], FS[k] = q.value, qs, fp.value, fs
+        self._check(self._lib.cart_superpixel_plane_classify(self._h, dp, ds, lp, ls, int(max_label), C.byref(pp), n, P, PS, F, FS,
+                                                             up, us, op, os_, _stream_ptr()), "cart_superpixel_plane_classify")
+        return uns, out
+
     # ---- depth module (reference src/modules/depth.cpp:9-25) ----
     def reproject_depth(self, disp, Q):
         import torch
@@ -266,6 +292,67 @@ class DevicePlaneSchedule:
     def close(self):
         if getattr(self, "_h", None):
             self._lib.cart_plane_schedule_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Superpixels:
+    """The reference's ContourRelaxation object (persistent label image + relax), cart_superpixels_* in the C ABI.
+    Label images are uint16; torch tensors carry them as int16 (same bits)."""
+
+    def __init__(self, engine, block_size=12, direct_clique_cost=0.5, diagonal_clique_cost=None, compactness_weight=0.1,
+                 progressive_compactness_cost=0.0, image_weight=1.5, disparity_weight=1.0, block_h=None):
+        self._eng = engine
+        self._lib = engine._lib
+        p = SuperpixelParams(direct_clique_cost, direct_clique_cost / np.sqrt(2.0) if diagonal_clique_cost is None else diagonal_clique_cost,
+                             compactness_weight, progressive_compactness_cost, image_weight, disparity_weight)
+        self.params = p
+        self._h = C.c_void_p()
+        rc = self._lib.cart_superpixels_create(engine._h, C.byref(p), int(block_size), int(block_h or block_size), C.byref(self._h))
+        if rc != 0:
+            raise EngineError("cart_superpixels_create: " + self._lib.cart_last_error(engine._h).decode())
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what}: " + self._lib.cart_last_error(self._eng._h).decode())
+
+    @property
+    def max_label(self):
+        return self._lib.cart_superpixels_max_label(self._h)
+
+    def reset(self):
+        self._check(self._lib.cart_superpixels_reset(self._h, _stream_ptr()), "cart_superpixels_reset")
+
+    def set_labels(self, labels, max_label_id):
+        _, p, s, _ = _geom(labels, 1)
+        if labels.element_size() != 2:
+            raise EngineError("labels must be a 16-bit tensor")
+        self._check(self._lib.cart_superpixels_set_labels(self._h, p, s, int(max_label_id), _stream_ptr()), "cart_superpixels_set_labels")
+
+    def relax(self, image, deriv2, iterations):
+        """image: uint8 [h,w,3] BGR or [h,w] gray; deriv2: int16 [h,w,2] or None -> labels int16-viewed uint16 [h,w]."""
+        import torch
+        ch = 3 if image.dim() == 3 else 1
+        _, ip, is_, _ = _geom(image, 2 if ch == 3 else 1)
+        if tuple(image.shape[:2]) != (self._eng.height, self._eng.width):
+            raise EngineError("image shape does not match the engine")
+        dp, ds = C.c_void_p(None), 0
+        if deriv2 is not None:
+            _, dp, ds, _ = _geom(deriv2, 2)
+        out = torch.empty((self._eng.height, self._eng.width), dtype=torch.int16, device=image.device)
+        _, op, os_, _ = _geom(out, 1)
+        self._check(self._lib.cart_superpixels_relax(self._h, ip, is_, ch, dp, ds, int(iterations), op, os_, _stream_ptr()),
+                    "cart_superpixels_relax")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cart_superpixels_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,6 +1,7 @@
 // cart_engine.hip -- C-ABI implementation (include/cart_engine.h): workspace pool, stage
 // sequencing and the host-side peak finder.  No exceptions cross the ABI and nothing exits.
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,7 @@ struct cart_engine {
     uint32_t *right_pk = nullptr;
     int16_t *tmp_a = nullptr, *tmp_b = nullptr;  // tight s16 planes (interpolate ping-pong)
     int32_t *ccl_work = nullptr;
+    unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     std::mutex mu;
     std::condition_variable cv;
@@ -272,7 +274,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
@@ -634,6 +636,216 @@ int cart_reproject_depth(cart_engine *e, int n_frames, const int16_t *disp, size
     QMatrix q;
     std::memcpy(q.q, Q, sizeof(q.q));
     launch_reproject(disp, disp_step, disp_frame_stride, q, xyz, xyz_step, xyz_frame_stride, g.w, g.h, n_frames, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- superpixels (replaces ContourRelaxation + SuperPixelModule's device work; oracle S13/S14) ----
+struct cart_superpixels {
+    cart_engine *engine = nullptr;
+    cart_superpixel_params params;
+    int block_w = 0, block_h = 0;
+    int max_label_id = 0;        // number of initial blocks (labels are < max_label_id)
+    uint16_t *labels[2] = {nullptr, nullptr};  // tight [h][w]; labels[cur] is the state
+    int cur = 0;
+    uint32_t *ycc = nullptr;
+    long long *stats = nullptr, *delta = nullptr;  // [kSpStatRows][kSpMaxLabels]-capacity
+    double *costs = nullptr;
+    int *max_seen = nullptr;
+    std::mutex mu;               // serialises calls (superpixels.cu:97-99)
+    hipEvent_t done = nullptr;   // orders successive calls that arrive on different streams
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+
+namespace {
+int sp_enter(cart_superpixels *sp, hipStream_t stream) {
+    if (sp->used && sp->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, sp->done, 0));
+    return 0;
+}
+void sp_leave(cart_superpixels *sp, hipStream_t stream) {
+    (void)hipEventRecord(sp->done, stream);
+    sp->last_stream = stream;
+    sp->used = true;
+}
+}  // namespace
+
+void cart_superpixel_default_params(cart_superpixel_params *p) {
+    if (!p) return;
+    p->direct_clique_cost = 0.5;                       // cartconfig.cpp:128
+    p->diagonal_clique_cost = 0.5 / std::sqrt(2.0);    // cartconfig.cpp:129
+    p->compactness_weight = 0.1;                       // cartconfig.cpp:130
+    p->progressive_compactness_cost = 0.0;             // cartconfig.cpp:131
+    p->image_weight = 1.5;                             // cartconfig.cpp:132
+    p->disparity_weight = 1.0;                         // cartconfig.cpp:133
+}
+
+int cart_superpixels_create(cart_engine *e, const cart_superpixel_params *params, int block_w, int block_h, cart_superpixels **out) {
+    if (!e || !params || !out) return fail("bad arguments");
+    if (block_w < 1 || block_h < 1) return fail("blockSize must be more than 1");                      // superpixels.cu:37-39
+    if (params->direct_clique_cost < 0) return fail("directCliqueCost must be non-negative");          // superpixels.cu:41-43
+    if (params->compactness_weight < 0 || params->image_weight < 0 || params->disparity_weight < 0)
+        return fail("weight must be non-negative");                                                    // superpixels.cu:45-47
+    const Geometry &g = e->g;
+    if (g.w < block_w || g.h < block_h) return fail("image smaller than one block");                   // initialization.cu:42
+    const long blocks = (long)((g.w + block_w - 1) / block_w) * ((g.h + block_h - 1) / block_h);
+    if (blocks >= kSpMaxLabels) return fail("too many superpixels: number of blocks must be < 16384 (increase block size)");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    cart_superpixels *sp = new (std::nothrow) cart_superpixels;
+    if (!sp) return fail("out of host memory");
+    sp->engine = e; sp->params = *params; sp->block_w = block_w; sp->block_h = block_h; sp->max_label_id = (int)blocks;
+    const size_t stat_elems = (size_t)kSpStatRows * kSpMaxLabels;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&sp->labels[0]), g.npx * 2) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->labels[1]), g.npx * 2) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->ycc), g.npx * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->stats), stat_elems * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->delta), stat_elems * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->costs), (size_t)kSpChannels * kSpMaxLabels * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->max_seen), sizeof(int)) == hipSuccess &&
+              hipEventCreateWithFlags(&sp->done, hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        launch_sp_block_init(sp->labels[0], g.w, g.h, block_w, block_h, nullptr);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (!ok) {
+        cart_superpixels_destroy(sp);
+        return fail("allocating the superpixel state failed");
+    }
+    *out = sp;
+    return 0;
+}
+
+void cart_superpixels_destroy(cart_superpixels *sp) {
+    if (!sp) return;
+    (void)hipDeviceSynchronize();
+    void *bufs[] = {sp->labels[0], sp->labels[1], sp->ycc, sp->stats, sp->delta, sp->costs, sp->max_seen};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (sp->done) (void)hipEventDestroy(sp->done);
+    delete sp;
+}
+
+int cart_superpixels_max_label(const cart_superpixels *sp) { return sp ? sp->max_label_id : -1; }
+
+int cart_superpixels_reset(cart_superpixels *sp, void *stream_) {
+    if (!sp) return fail("superpixels is NULL");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const Geometry &g = sp->engine->g;
+    HIP_TRY(hipSetDevice(sp->engine->params.device_id));
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp_enter(sp, stream)) return -1;
+    launch_sp_block_init(sp->labels[sp->cur], g.w, g.h, sp->block_w, sp->block_h, stream);
+    sp->max_label_id = ((g.w + sp->block_w - 1) / sp->block_w) * ((g.h + sp->block_h - 1) / sp->block_h);
+    sp_leave(sp, stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_superpixels_set_labels(cart_superpixels *sp, const uint16_t *labels, size_t labels_step, int max_label_id, void *stream_) {
+    if (!sp || !labels) return fail("bad arguments");
+    if (max_label_id < 1 || max_label_id >= kSpMaxLabels) return fail("max_label_id must be in [1, 16384)");
+    const Geometry &g = sp->engine->g;
+    if (labels_step < (size_t)g.w * 2 || (labels_step & 1)) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(sp->engine->params.device_id));
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp_enter(sp, stream)) return -1;
+    // the copy goes to the spare buffer and becomes the state only if every label is in range
+    uint16_t *spare = sp->labels[sp->cur ^ 1];
+    HIP_TRY(hipMemsetAsync(sp->max_seen, 0, sizeof(int), stream));
+    launch_sp_copy(labels, labels_step, spare, (size_t)g.w * 2, g.w, g.h, sp->max_seen, stream);
+    int seen = 0;
+    HIP_TRY(hipMemcpyAsync(&seen, sp->max_seen, sizeof(int), hipMemcpyDeviceToHost, stream));
+    sp_leave(sp, stream);
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (seen >= max_label_id) return fail("label image holds a label >= max_label_id");
+    sp->cur ^= 1;
+    sp->max_label_id = max_label_id;
+    return 0;
+}
+
+int cart_superpixels_relax(cart_superpixels *sp, const uint8_t *image, size_t image_step, int channels, const int16_t *deriv2,
+                           size_t deriv2_step, int iterations, uint16_t *labels_out, size_t labels_out_step, void *stream_) {
+    if (!sp) return fail("superpixels is NULL");
+    if (!image) return fail("NULL pointer");
+    if (channels != 1 && channels != 3) return fail("channels must be 1 or 3");
+    if (iterations < 0) return fail("iterations must be >= 0");
+    const Geometry &g = sp->engine->g;
+    const cart_superpixel_params &p = sp->params;
+    if (image_step < (size_t)g.w * channels) return fail("bad step");
+    if (p.disparity_weight > 0) {
+        if (!deriv2) return fail("the disparity feature needs the 2-channel disparity derivative image");
+        if (deriv2_step < (size_t)g.w * 4 || (deriv2_step & 3) || (reinterpret_cast<uintptr_t>(deriv2) & 3)) return fail("bad step");
+    }
+    if (labels_out && (labels_out_step < (size_t)g.w * 2 || (labels_out_step & 1))) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(sp->engine->params.device_id));
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp_enter(sp, stream)) return -1;
+    const int ld = sp->max_label_id + 1;
+    SpRelaxArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ycc = sp->ycc; a.deriv = p.disparity_weight > 0 ? deriv2 : nullptr; a.deriv_step = deriv2_step;
+    a.stats = sp->stats; a.costs = sp->costs; a.delta = sp->delta; a.ld = ld; a.w = g.w; a.h = g.h;
+    a.ch_mask = (p.compactness_weight > 0 ? 0x03u : 0u) | (p.disparity_weight > 0 ? 0x0cu : 0u) | (p.image_weight > 0 ? 0x70u : 0u);
+    a.direct = p.direct_clique_cost; a.diagonal = p.diagonal_clique_cost; a.w_comp = p.compactness_weight;
+    a.prog = p.progressive_compactness_cost; a.w_img = p.image_weight; a.w_disp = p.disparity_weight;
+    launch_sp_ycrcb(image, image_step, channels, sp->ycc, g.w, g.h, stream);
+    HIP_TRY(hipMemsetAsync(sp->stats, 0, (size_t)kSpStatRows * ld * 8, stream));
+    HIP_TRY(hipMemsetAsync(sp->delta, 0, (size_t)kSpStatRows * ld * 8, stream));
+    a.cur = sp->labels[sp->cur]; a.next = sp->labels[sp->cur ^ 1];
+    launch_sp_stats(a, stream);
+    launch_sp_fold(sp->stats, sp->delta, sp->costs, ld, a.ch_mask, stream);
+    for (int it = 0; it < iterations; ++it) {
+        a.cur = sp->labels[sp->cur]; a.next = sp->labels[sp->cur ^ 1];
+        launch_sp_relax(a, stream);
+        launch_sp_fold(sp->stats, sp->delta, sp->costs, ld, a.ch_mask, stream);
+        sp->cur ^= 1;
+    }
+    if (labels_out) launch_sp_copy(sp->labels[sp->cur], (size_t)g.w * 2, labels_out, labels_out_step, g.w, g.h, nullptr, stream);
+    sp_leave(sp, stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_superpixel_plane_classify(cart_engine *e, const int16_t *deriv2, size_t deriv2_step, const uint16_t *labels, size_t labels_step,
+                                   int max_label, const cart_plane_params *params, int n_prev, const uint8_t *const *prev_planes,
+                                   const size_t *prev_steps, const int16_t *const *flows, const size_t *flow_steps,
+                                   uint8_t *planes_unsmoothed, size_t planes_unsmoothed_step, uint8_t *planes, size_t planes_step,
+                                   void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!deriv2 || !labels || !params || !planes_unsmoothed || !planes) return fail("NULL pointer");
+    if (max_label < 1 || max_label > kSpMaxLabels) return fail("max_label must be in [1, 16384]");
+    if (n_prev < 0 || n_prev > CART_MAX_TEMPORAL) return fail("n_prev must be in [0, CART_MAX_TEMPORAL]");
+    if (n_prev > 0 && (!prev_planes || !prev_steps || !flows || !flow_steps)) return fail("NULL table");
+    const Geometry &g = e->g;
+    if (deriv2_step < (size_t)g.w * 4 || (deriv2_step & 3) || labels_step < (size_t)g.w * 2 || (labels_step & 1) ||
+        planes_unsmoothed_step < (size_t)g.w || planes_step < (size_t)g.w)
+        return fail("bad step");
+    SpClassifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.t.n_prev = n_prev;
+    for (int k = 0; k < n_prev; ++k) {
+        if (!prev_planes[k] || !flows[k]) return fail("NULL entry in the temporal tables");
+        if (prev_steps[k] < (size_t)g.w || flow_steps[k] < (size_t)g.w * 4 || (flow_steps[k] & 3)) return fail("bad step in the temporal tables");
+        a.t.prev[k] = prev_planes[k]; a.t.prev_step[k] = prev_steps[k]; a.t.flow[k] = flows[k]; a.t.flow_step[k] = flow_steps[k];
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->sp_votes) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sp_votes), e->slots.size() * (size_t)kSpMaxLabels * 3 * sizeof(unsigned)));
+    }
+    Lease lease;
+    if (acquire(e, 1, stream, &lease)) return -1;
+    a.deriv = deriv2; a.deriv_step = deriv2_step; a.labels = labels; a.labels_step = labels_step;
+    a.w = g.w; a.h = g.h; a.max_label = max_label; a.p = *params;
+    a.unsmoothed = planes_unsmoothed; a.unsmoothed_step = planes_unsmoothed_step; a.planes = planes; a.planes_step = planes_step;
+    a.votes = e->sp_votes + (size_t)lease.s0 * kSpMaxLabels * 3;
+    hipError_t err = hipMemsetAsync(a.votes, 0, (size_t)max_label * 3 * sizeof(unsigned), stream);
+    if (err == hipSuccess) launch_sp_classify(a, stream);
+    release(lease);
+    if (err != hipSuccess) return fail(std::string("hipMemsetAsync: ") + hipGetErrorString(err));
     HIP_TRY(hipGetLastError());
     return 0;
 }

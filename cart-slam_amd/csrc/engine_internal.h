@@ -98,6 +98,42 @@ struct QMatrix { float q[16]; };
 void launch_reproject(const int16_t *disp, size_t step, size_t fs, const QMatrix &Q, float *xyz, size_t ostep, size_t ofs, int w, int h,
                       int n_frames, hipStream_t s);
 
+// ---- superpixels (superpixel_kernels.hip) ----
+constexpr int kSpChannels = 7;    // 0 x, 1 y | 2,3 disparity-derivative ch0,ch1 | 4,5,6 Y,Cr,Cb
+constexpr int kSpStatRows = 15;   // 0 pixel count | 1..7 channel sums | 8..14 channel sums of squares
+constexpr int kSpMaxLabels = 16384;  // the reference reserves 1 << 14 as its out-of-image marker (contourrelaxation.cu:21)
+struct SpRelaxArgs {
+    const uint16_t *cur;     // tight [h][w]
+    uint16_t *next;
+    const uint32_t *ycc;     // tight [h][w], Y | Cr << 8 | Cb << 16
+    const int16_t *deriv;    // caller's 2-channel derivative image (NULL when the disparity feature is off)
+    size_t deriv_step;       // bytes
+    long long *stats;        // [kSpStatRows][ld]
+    const double *costs;     // [kSpChannels][ld]
+    long long *delta;        // [kSpStatRows][ld]
+    int ld;                  // max_label_id + 1
+    int w, h;
+    unsigned ch_mask;        // bit ch = channel takes part
+    double direct, diagonal, w_comp, prog, w_img, w_disp;
+};
+void launch_sp_block_init(uint16_t *labels, int w, int h, int bw, int bh, hipStream_t s);
+void launch_sp_ycrcb(const uint8_t *img, size_t step, int channels, uint32_t *ycc, int w, int h, hipStream_t s);
+void launch_sp_stats(const SpRelaxArgs &a, hipStream_t s);
+void launch_sp_fold(long long *stats, long long *delta, double *costs, int ld, unsigned ch_mask, hipStream_t s);
+void launch_sp_relax(const SpRelaxArgs &a, hipStream_t s);
+void launch_sp_copy(const uint16_t *src, size_t src_step, uint16_t *dst, size_t dst_step, int w, int h, int *max_seen, hipStream_t s);
+struct SpClassifyArgs {
+    const int16_t *deriv; size_t deriv_step;      // 2-channel, bytes
+    const uint16_t *labels; size_t labels_step;   // bytes
+    int w, h, max_label;
+    cart_plane_params p;
+    TemporalArgs t;
+    uint8_t *unsmoothed; size_t unsmoothed_step;
+    uint8_t *planes; size_t planes_step;
+    unsigned *votes;                              // [max_label][3], zeroed by the caller
+};
+void launch_sp_classify(const SpClassifyArgs &a, hipStream_t s);
+
 int kernel_count();
 
 }  // namespace cart_amd

@@ -441,6 +441,6 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 18; }
+int kernel_count() { return 26; }  // 18 (SGM + post stages, template instances counted) + 8 superpixel kernels
 
 }  // namespace cart_amd

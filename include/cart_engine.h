@@ -168,6 +168,60 @@ int cart_reproject_depth(cart_engine *engine, int n_frames,
                          const int16_t *disp, size_t disp_step, size_t disp_frame_stride, const float Q[16],
                          float *xyz, size_t xyz_step, size_t xyz_frame_stride, void *stream);
 
+/* ---- superpixels ------------------------------------------------------------------------------
+ * replaces: contour::ContourRelaxation + contour::createBlockInitialization as driven by SuperPixelModule
+ * (src/modules/superpixels.cu:19-118, src/modules/superpixels/contourrelaxation/contourrelaxation.cu:324-447,
+ * initialization.cu:13-58, features/gaussian.cu, features/compactness.cu).  The object owns the persistent label
+ * image (ContourRelaxation::labelImage, contourrelaxation.hpp:47) and the per-label statistics workspaces; the
+ * features are the reference's three: compactness, disparity (2-channel derivative image), colour (YCrCb).  A weight
+ * <= 0 leaves the feature out (contourrelaxation.hpp:55-61).  Defaults of the JSON factory: cartconfig.cpp:121-133.
+ * Semantics: oracle S13/S14 (race-free Jacobi sweeps, statistics over the whole image, fixed log sequence). */
+typedef struct cart_superpixel_params {
+    double direct_clique_cost;              /* 0.5 */
+    double diagonal_clique_cost;            /* direct / sqrt(2) */
+    double compactness_weight;              /* 0.1 */
+    double progressive_compactness_cost;    /* 0.0 */
+    double image_weight;                    /* 1.5 */
+    double disparity_weight;                /* 1.0 */
+} cart_superpixel_params;
+void cart_superpixel_default_params(cart_superpixel_params *p);
+
+typedef struct cart_superpixels cart_superpixels;
+/* Allocates the state for the engine's image size and runs the block initialisation (superpixels.cu:57-59):
+ * label = (y / block_h) * ceil(w / block_w) + x / block_w, max_label_id = #blocks (must be < 16384). */
+int cart_superpixels_create(cart_engine *engine, const cart_superpixel_params *params, int block_w, int block_h,
+                            cart_superpixels **out);
+void cart_superpixels_destroy(cart_superpixels *sp);
+/* Re-runs the block initialisation (the reset every `reset_iterations` frames, superpixels.cu:104-112). */
+int cart_superpixels_reset(cart_superpixels *sp, void *stream);
+/* ContourRelaxation::setLabelImage (contourrelaxation.cu:332-335): replaces the state with the caller's CV_16UC1
+ * label image; every label must be < max_label_id (checked; synchronises `stream`). */
+int cart_superpixels_set_labels(cart_superpixels *sp, const uint16_t *labels, size_t labels_step, int max_label_id,
+                                void *stream);
+/* ContourRelaxation::relax (contourrelaxation.cu:337-447) including the YCrCb conversion the module does first
+ * (superpixels.cu:75-82): `image` = the frame's reference image, 3-channel BGR (or 1-channel gray, treated as
+ * B=G=R); `deriv2` = CV_16SC2 "disparity_derivative" (may be NULL iff disparity_weight <= 0).  Runs `iterations`
+ * sweeps on the state and copies the resulting label image to labels_out (CV_16UC1; may be NULL).  Calls on one
+ * object are serialised in call order (the reference locks a mutex, superpixels.cu:97-99). */
+int cart_superpixels_relax(cart_superpixels *sp, const uint8_t *image, size_t image_step, int channels,
+                           const int16_t *deriv2, size_t deriv2_step, int iterations,
+                           uint16_t *labels_out, size_t labels_out_step, void *stream);
+/* superpixels_max_label blackboard value (superpixels.hpp:12). */
+int cart_superpixels_max_label(const cart_superpixels *sp);
+
+/* replaces: performSuperPixelClassifications + classifyPlanes launches (sp_planeseg.cu:27-178, 327-328).
+ * deriv2 = CV_16SC2 derivative image (channel 0 is classified), labels = CV_16UC1 superpixels, max_label =
+ * superpixels_max_label; n_prev/prev_planes/flows = the temporal tables the module builds (sp_planeseg.cu:243-300,
+ * same layout as cart_plane_temporal_vote; n_prev = 0 -> no temporal vote).  Outputs: planes_unsmoothed = per-pixel
+ * class before any vote ("planes_unsmoothed"), planes = per-superpixel majority ("planes"). */
+int cart_superpixel_plane_classify(cart_engine *engine, const int16_t *deriv2, size_t deriv2_step,
+                                   const uint16_t *labels, size_t labels_step, int max_label,
+                                   const cart_plane_params *params, int n_prev,
+                                   const uint8_t *const *prev_planes, const size_t *prev_steps,
+                                   const int16_t *const *flows, const size_t *flow_steps,
+                                   uint8_t *planes_unsmoothed, size_t planes_unsmoothed_step,
+                                   uint8_t *planes, size_t planes_step, void *stream);
+
 /* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
 

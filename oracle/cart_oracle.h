@@ -51,6 +51,18 @@
  *  S12 CCL      (no reference counterpart) 4-connected components over the plane
  *                 label map for labels {0,1}; component id = smallest linear index
  *                 y*W+x in the component; label-2 (UNKNOWN) pixels get -1.
+ *  S13 superpixels (contour relaxation; reference: src/modules/superpixels.cu and superpixels/contourrelaxation/): the reference's
+ *                 result depends on racy featureCost refreshes, nvcc FMA contraction and CUDA's log(); the spec is the
+ *                 race-free intent: per iteration EVERY pixel picks, from the unique labels of its in-image 3x3
+ *                 neighbourhood (visited dx-major: (-1,-1),(-1,0),(-1,1),(0,-1),...,(1,1)), the first one of minimal cost,
+ *                 all costs evaluated on the label image and label statistics of the iteration start (Jacobi); then all
+ *                 changes are applied and the statistics (exact integer sums) and per-label feature costs refreshed.
+ *                 Statistics cover the whole image (the reference's floor()ed init grid, contourrelaxation.cu:371, drops
+ *                 the right/bottom strips).  All arithmetic is IEEE double, no FMA contraction, operations in the
+ *                 reference's source order; log() is cart_oracle_log below (a fixed sequence of IEEE operations, so that
+ *                 CPU and GPU agree bit for bit).
+ *  S14 YCrCb    = OpenCV 8-bit BGR2YCrCb: Y as S1; Cr = ((R-Y)*11682 + (128<<14) + 8192) >> 14;
+ *                 Cb = ((B-Y)*9241 + (128<<14) + 8192) >> 14, arithmetic shift, saturated to u8; stored (Y,Cr,Cb).
  */
 #ifndef CART_ORACLE_H
 #define CART_ORACLE_H
@@ -146,6 +158,41 @@ void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float 
 
 /* a-11 (S12). Returns the number of components. */
 int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids);
+
+/* ---- superpixels + superpixel plane labelling ------------------------------------------------- */
+
+/* cartconfig.cpp:121-133 / superpixels.hpp:16-27 */
+typedef struct {
+    double direct_clique_cost, diagonal_clique_cost;
+    double compactness_weight, progressive_compactness_cost;
+    double image_weight, disparity_weight;
+} cart_oracle_sp_params;
+
+/* S14; bgr pitched (3 B/px), out tight [h][w][3] = (Y,Cr,Cb). superpixels.cu:81 */
+void cart_oracle_bgr2ycrcb(const uint8_t *bgr, size_t src_step, int w, int h, uint8_t *ycrcb);
+
+/* initialization.cu:13-58: label = (y/bh)*ceil(w/bw) + x/bw; returns maxLabelId = ceil(w/bw)*ceil(h/bh). */
+int cart_oracle_sp_block_init(int w, int h, int block_w, int block_h, uint16_t *labels);
+
+/* S13 log for x > 0, finite, normal: x = m*2^e, m in (sqrt(.5), sqrt(2)] (m > 0x1.6a09e667f3bcdp+0 is halved),
+ * s = (m-1)/(m+1), z = s*s, p = Horner over z of c_k = 1.0/(2k+1), k = 11..0, r = (2*s)*p,
+ * log = e*0x1.62e42fee00000p-1 + (r + e*0x1.a39ef35793c76p-33). */
+double cart_oracle_log(double x);
+
+/* S13: contourrelaxation.cu:248-294 (performRelaxation), :296-322 (updateLabels), features/gaussian.cu,
+ * features/compactness.cu.  labels [h][w] u16 in/out (all < max_label_id < 16384); ycrcb tight [h][w][3];
+ * deriv2 tight [h][w][2] s16 (ch0 vertical, ch1 horizontal; may be NULL iff disparity_weight <= 0).
+ * Returns the total number of label changes, or -1 on bad arguments. */
+long cart_oracle_sp_relax(const cart_oracle_sp_params *p, uint16_t *labels, int w, int h, int max_label_id,
+                          const uint8_t *ycrcb, const int16_t *deriv2, int iterations);
+
+/* sp_planeseg.cu:27-128 (per-pixel classification of deriv ch0, optional temporal vote with weight 2 for the current
+ * frame, u16 per-label vote counts) + :130-178 (per-label majority, UNKNOWN wins ties, HORIZONTAL needs > max(U,V)).
+ * planes_unsmoothed = the per-pixel classification BEFORE the temporal vote (what the kernel stores, :75);
+ * planes = the per-superpixel result. */
+void cart_oracle_sp_classify(const int16_t *deriv2, const uint16_t *labels, int w, int h, int max_label,
+                             const cart_oracle_plane_params *params, int n_prev, const uint8_t *const *prev_planes,
+                             const int16_t *const *flows, uint8_t *planes_unsmoothed, uint8_t *planes);
 
 #ifdef __cplusplus
 }

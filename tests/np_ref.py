@@ -255,3 +255,158 @@ def find_peaks(data):
         return (1 << 31) - 1 if p["died"] < 0 else data[p["born"]] - data[p["died"]]
     peaks.sort(key=lambda p: -pers(p))  # python's sort is stable
     return [(p["born"], p["died"], p["left"], p["right"]) for p in peaks]
+
+
+# ---- superpixels (S13 / S14): pure Python, tiny images only --------------------------------------------------------
+def bgr2ycrcb(bgr):
+    b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
+    y = (1868 * b + 9617 * g + 4899 * r + 8192) >> 14
+    cr = ((r - y) * 11682 + (128 << 14) + 8192) >> 14
+    cb = ((b - y) * 9241 + (128 << 14) + 8192) >> 14
+    return np.stack([np.clip(c, 0, 255) for c in (y, cr, cb)], axis=-1).astype(np.uint8)
+
+
+def spec_log(x):
+    """S13 log, written from the header text (Python floats are IEEE doubles, no contraction)."""
+    import struct
+    bits = struct.unpack("<Q", struct.pack("<d", x))[0]
+    e = (bits >> 52) - 1023
+    m = struct.unpack("<d", struct.pack("<Q", (bits & ((1 << 52) - 1)) | (1023 << 52)))[0]
+    if m > float.fromhex("0x1.6a09e667f3bcdp+0"):
+        m, e = m * 0.5, e + 1
+    s = (m - 1.0) / (m + 1.0)
+    z = s * s
+    p = 1.0 / 23.0
+    for k in range(10, -1, -1):
+        p = p * z + 1.0 / float(2 * k + 1)
+    r = (2.0 * s) * p
+    return float(e) * float.fromhex("0x1.62e42fee00000p-1") + (r + float(e) * float.fromhex("0x1.a39ef35793c76p-33"))
+
+
+def _gauss(n, s, q):
+    if n == 0:
+        return 0.0
+    a, b = float(q) / float(n), float(s) / float(n)
+    var = a - b * b
+    if not var >= 1.0 / 12.0:
+        var = 1.0 / 12.0
+    return (float(n) / 2 * spec_log(float.fromhex("0x1.921fb54442d18p+2") * var)) + (float(n) / 2)
+
+
+def _compact(n, s, q):
+    if n == 0:
+        return 0.0
+    return float(q) - (float(s) * float(s)) / float(n)
+
+
+def sp_relax(labels, ycrcb, deriv2, iterations, direct=0.5, diagonal=0.5 / np.sqrt(2.0), compactness=0.1, progressive=0.0,
+             image=1.5, disparity=1.0):
+    """Statistics are rebuilt from scratch before every iteration (the oracle updates them incrementally)."""
+    lab = labels.astype(np.int64).copy()
+    h, w = lab.shape
+    groups = []  # (weight, divisor, channel value getters, cost fn, is_compactness)
+    if compactness > 0:
+        groups.append((compactness, None, [lambda x, y: x, lambda x, y: y], _compact, True))
+    if disparity > 0:
+        groups.append((disparity, 2.0, [lambda x, y, c=c: int(deriv2[y, x, c]) for c in range(2)], _gauss, False))
+    if image > 0:
+        groups.append((image, 3.0, [lambda x, y, c=c: int(ycrcb[y, x, c]) for c in range(3)], _gauss, False))
+    for _ in range(iterations):
+        cnt = {}
+        sums = [[{} for _ in g[2]] for g in groups]
+        sqs = [[{} for _ in g[2]] for g in groups]
+        for y in range(h):
+            for x in range(w):
+                L = int(lab[y, x])
+                cnt[L] = cnt.get(L, 0) + 1
+                for gi, g in enumerate(groups):
+                    for ci, get in enumerate(g[2]):
+                        v = get(x, y)
+                        sums[gi][ci][L] = sums[gi][ci].get(L, 0) + v
+                        sqs[gi][ci][L] = sqs[gi][ci].get(L, 0) + v * v
+        new = lab.copy()
+        for y in range(h):
+            for x in range(w):
+                nb = {}
+                order = []
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        xx, yy = x + dx, y + dy
+                        if 0 <= xx < w and 0 <= yy < h:
+                            L = int(lab[yy, xx])
+                            nb[(dx, dy)] = L
+                            if L not in order:
+                                order.append(L)
+                O = int(lab[y, x])
+                if len(order) < 2:
+                    continue
+                best, best_cost = O, None
+                for P in order:
+                    nd = sum(1 for k in ((-1, 0), (1, 0), (0, -1), (0, 1)) if k in nb and nb[k] != P)
+                    ng = sum(1 for k in ((-1, -1), (-1, 1), (1, -1), (1, 1)) if k in nb and nb[k] != P)
+                    cost = nd * direct + ng * diagonal
+                    for gi, (wgt, div, getters, fn, is_c) in enumerate(groups):
+                        f = 0.0
+                        for L in order:
+                            n = cnt[L]
+                            delta = 0
+                            if O != P and L == O:
+                                delta = -1
+                            elif O != P and L == P:
+                                delta = 1
+                            n += delta
+                            if n == 0:
+                                continue
+                            ks = []
+                            for ci, get in enumerate(getters):
+                                v = get(x, y)
+                                ks.append(fn(n, sums[gi][ci][L] + delta * v, sqs[gi][ci][L] + delta * v * v))
+                            if is_c:
+                                f += ks[0] + ks[1]
+                            else:
+                                for k in ks:
+                                    f += k
+                        if is_c:
+                            if progressive > 0.0:
+                                f *= 1.0 + progressive * (float(h) - float(y)) / float(h)
+                            cost += wgt * f
+                        else:
+                            cost += wgt * (f / div)
+                    if best_cost is None or cost < best_cost:
+                        best, best_cost = P, cost
+                new[y, x] = best
+        lab = new
+    return lab.astype(np.uint16)
+
+
+def sp_classify(deriv2, labels, max_label, params, prev_planes=(), flows=()):
+    hmin, hmax, vmin, vmax = params[:4]
+    h, w = labels.shape
+    d = deriv2[..., 0].astype(np.int64)
+    uns = np.full((h, w), 2, np.uint8)
+    uns[(d != INVALID) & (d >= vmin) & (d < vmax)] = 1
+    uns[(d != INVALID) & (d >= hmin) & (d < hmax)] = 0
+    voted = uns.copy()
+    if len(prev_planes):
+        for y in range(h):
+            for x in range(w):
+                v = [0, 0, 0]
+                v[uns[y, x]] += 2
+                px, py = x, y
+                for k in range(len(prev_planes)):
+                    px -= int(flows[k][y, x, 0]) >> 5
+                    py -= int(flows[k][y, x, 1]) >> 5
+                    if 0 <= px < w and 0 <= py < h:
+                        v[prev_planes[k][py, px]] += 1
+                p = 0 if v[0] > v[1] else 1
+                voted[y, x] = 2 if v[p] < v[2] else p
+    votes = np.zeros((max_label, 3), np.int64)
+    np.add.at(votes, (labels.astype(np.int64).ravel(), voted.astype(np.int64).ravel()), 1)
+    votes &= 0xFFFF
+    assign = np.full(max_label, 2, np.uint8)
+    mx = votes[:, 2].copy()
+    sel = votes[:, 1] > mx
+    assign[sel] = 1
+    mx[sel] = votes[sel, 1]
+    assign[votes[:, 0] > mx] = 0
+    return uns, assign[labels.astype(np.int64)]

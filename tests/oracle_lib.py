@@ -30,7 +30,7 @@ _lib = None
 
 
 def build():
-    src_time = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("cart_oracle.c", "cart_oracle.h"))
+    src_time = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("cart_oracle.c", "cart_oracle_sp.c", "cart_oracle.h"))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < src_time:
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
 
@@ -45,6 +45,10 @@ def lib():
         _lib.cart_oracle_find_peaks.restype = C.c_int
         _lib.cart_oracle_histogram_peak_params.restype = C.c_int
         _lib.cart_oracle_ccl.restype = C.c_int
+        _lib.cart_oracle_sp_block_init.restype = C.c_int
+        _lib.cart_oracle_sp_relax.restype = C.c_long
+        _lib.cart_oracle_log.restype = C.c_double
+        _lib.cart_oracle_log.argtypes = [C.c_double]
     return _lib
 
 
@@ -211,3 +215,61 @@ def temporal_vote(planes, prev_planes, flows):
     o = np.empty((h, w), np.uint8)
     lib().cart_oracle_temporal_vote(_p(np.ascontiguousarray(planes, np.uint8)), w, h, n, P, F, _p(o))
     return o
+
+
+# ---- superpixels (S13/S14) -------------------------------------------------------------------------------------
+class SpParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("direct_clique_cost", "diagonal_clique_cost", "compactness_weight",
+                                          "progressive_compactness_cost", "image_weight", "disparity_weight")]
+
+
+def sp_params(direct=0.5, diagonal=None, compactness=0.1, progressive=0.0, image=1.5, disparity=1.0):
+    """Defaults of the reference's JSON factory (cartconfig.cpp:121-133)."""
+    return SpParams(direct, direct / np.sqrt(2.0) if diagonal is None else diagonal, compactness, progressive, image, disparity)
+
+
+def bgr2ycrcb(bgr):
+    h, w, _ = bgr.shape
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty((h, w, 3), np.uint8)
+    lib().cart_oracle_bgr2ycrcb(_p(bgr), C.c_size_t(w * 3), w, h, _p(out))
+    return out
+
+
+def sp_block_init(w, h, bw, bh):
+    labels = np.empty((h, w), np.uint16)
+    mx = lib().cart_oracle_sp_block_init(w, h, bw, bh, _p(labels))
+    return labels, mx
+
+
+def log(x):
+    return lib().cart_oracle_log(float(x))
+
+
+def sp_relax(params, labels, max_label_id, ycrcb, deriv2, iterations):
+    """-> (new labels, number of label changes)."""
+    h, w = labels.shape
+    out = np.ascontiguousarray(labels, np.uint16).copy()
+    yc = None if ycrcb is None else np.ascontiguousarray(ycrcb, np.uint8)
+    d2 = None if deriv2 is None else np.ascontiguousarray(deriv2, np.int16)
+    n = lib().cart_oracle_sp_relax(C.byref(params), _p(out), w, h, int(max_label_id), _p(yc) if yc is not None else None,
+                                   _p(d2) if d2 is not None else None, int(iterations))
+    if n < 0:
+        raise ValueError("cart_oracle_sp_relax: bad arguments")
+    return out, n
+
+
+def sp_classify(deriv2, labels, max_label, params, prev_planes=(), flows=()):
+    h, w = labels.shape
+    d2 = np.ascontiguousarray(deriv2, np.int16)
+    lb = np.ascontiguousarray(labels, np.uint16)
+    pp = params if isinstance(params, PlaneParams) else PlaneParams(*params)
+    n = len(prev_planes)
+    prevs = [np.ascontiguousarray(a, np.uint8) for a in prev_planes]
+    fl = [np.ascontiguousarray(a, np.int16) for a in flows]
+    pa = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in prevs])
+    fa = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in fl])
+    uns = np.empty((h, w), np.uint8)
+    out = np.empty((h, w), np.uint8)
+    lib().cart_oracle_sp_classify(_p(d2), _p(lb), w, h, int(max_label), C.byref(pp), n, pa, fa, _p(uns), _p(out))
+    return uns, out

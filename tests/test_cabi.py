@@ -32,6 +32,12 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from cartslam import _lib
     assert C.sizeof(_lib.EngineParams) == 12 * 4 and C.sizeof(_lib.PlaneParams) == 6 * 4
+    assert C.sizeof(_lib.SuperpixelParams) == 6 * 8
+    sp = _lib.SuperpixelParams()
+    _lib.load().cart_superpixel_default_params(C.byref(sp))
+    # cartconfig.cpp:128-133
+    assert (sp.direct_clique_cost, sp.compactness_weight, sp.progressive_compactness_cost, sp.image_weight, sp.disparity_weight) == (0.5, 0.1, 0.0, 1.5, 1.0)
+    assert sp.diagonal_clique_cost == 0.5 / np.sqrt(2.0)
     p = _lib.EngineParams()
     _lib.load().cart_engine_default_params(C.byref(p))
     # reference defaults: cartconfig.cpp:144-152, disparity.hpp:32, cartslam.hpp:4

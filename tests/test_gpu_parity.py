@@ -239,7 +239,7 @@ def test_ccl_hard_shapes(torch_cuda):
 def test_golden_fixtures(torch_cuda):
     torch = torch_cuda
     from cartslam import find_plane_params
-    files = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "road_*.npz")))
     assert files
     for f in files:
         z = np.load(f)

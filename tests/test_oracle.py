@@ -161,7 +161,7 @@ def test_find_peaks_and_params():
 
 
 def test_golden_fixtures():
-    files = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "road_*.npz")))
     assert files, "no golden fixtures committed"
     for f in files:
         z = np.load(f)
@@ -179,3 +179,112 @@ def test_golden_fixtures():
         assert (pl == z["planes"]).all(), f
         ids, n = O.ccl(pl)
         assert (ids == z["ccl_ids"]).all() and n == int(z["ccl_n"]), f
+
+
+# ---- superpixels (S13 / S14) ----------------------------------------------------------------------------------------
+def test_ycrcb_and_block_init_known_answers():
+    # OpenCV's documented 8-bit BGR2YCrCb values for the primaries (S14)
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [90, 90, 90]]], np.uint8)  # B, G, R, white, black, gray
+    want = np.array([[[29, 107, 255], [150, 21, 43], [76, 255, 85], [255, 128, 128], [0, 128, 128], [90, 128, 128]]], np.uint8)
+    assert (O.bgr2ycrcb(px) == want).all() and (N.bgr2ycrcb(px) == want).all()
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (13, 17, 3)).astype(np.uint8)
+    assert (O.bgr2ycrcb(img) == N.bgr2ycrcb(img)).all()
+    # initialization.cu:13-58: 10x7 image, 4x3 blocks -> 3 x 3 blocks, the last ones smaller
+    lab, mx = O.sp_block_init(10, 7, 4, 3)
+    assert mx == 9 and lab[0, 0] == 0 and lab[0, 9] == 2 and lab[6, 0] == 6 and lab[6, 9] == 8 and lab[2, 3] == 0 and lab[3, 4] == 4
+
+
+def test_spec_log():
+    import math
+    assert O.log(1.0) == 0.0
+    rng = np.random.default_rng(3)
+    for x in np.concatenate([rng.uniform(0.5, 4.0, 300), 10.0 ** rng.uniform(-1, 12, 300), [2.0 * math.pi / 12.0, 2.0, 0.5, math.sqrt(2.0)]]):
+        a = O.log(float(x))
+        assert a == N.spec_log(float(x))                       # the two restatements agree bit for bit
+        assert abs(a - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))   # and the sequence is a ~1 ulp log
+
+
+@pytest.mark.parametrize("w,h,bs,it,kw", [
+    (40, 30, 6, 3, {}),
+    (37, 29, 5, 4, dict(progressive=1.0, compactness=0.03)),
+    (33, 21, 8, 3, dict(disparity=0.0)),
+    (30, 20, 7, 2, dict(image=0.0, compactness=0.0)),
+    (26, 18, 4, 3, dict(image=0.0, compactness=0.0, disparity=0.0)),
+])
+def test_superpixel_relax_matches_python_restatement(w, h, bs, it, kw):
+    rng = np.random.default_rng(5 + w)
+    base = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2, 3)).astype(np.uint8)
+    bgr = np.kron(base, np.ones((4, 4, 1), np.uint8))[:h, :w]
+    bgr = np.clip(bgr.astype(int) + rng.integers(-6, 7, bgr.shape), 0, 255).astype(np.uint8)
+    yc = O.bgr2ycrcb(bgr)
+    d2 = rng.integers(-40, 40, (h, w, 2)).astype(np.int16)
+    d2[rng.random((h, w, 2)) < 0.1] = -32768
+    lab, mx = O.sp_block_init(w, h, bs, bs)
+    a, n = O.sp_relax(O.sp_params(**kw), lab, mx, yc, d2, it)
+    b = N.sp_relax(lab, yc, d2, it, **kw)
+    assert (a == b).all()
+    if kw.get("image", 1) or kw.get("disparity", 1):
+        assert n > 0
+    # sums over labels are conserved and no label id is invented
+    assert a.max() < mx and set(np.unique(a)) <= set(np.unique(lab))
+
+
+def test_superpixel_relax_properties_and_errors():
+    w, h = 48, 36
+    lab, mx = O.sp_block_init(w, h, 6, 6)
+    yc = np.full((h, w, 3), 77, np.uint8)
+    d2 = np.zeros((h, w, 2), np.int16)
+    same, n = O.sp_relax(O.sp_params(), lab, mx, yc, d2, 0)
+    assert n == 0 and (same == lab).all()
+    # a featureless frame: the regular block grid is a fixed point of the sweep (every move only adds clique cost)
+    flat, n = O.sp_relax(O.sp_params(), lab, mx, yc, d2, 3)
+    assert n == 0 and (flat == lab).all()
+    # a pixel of a foreign label in the middle of a block is absorbed by the first sweep
+    lab2 = lab.copy(); lab2[3, 3] = lab[3, 20]
+    fixed, n = O.sp_relax(O.sp_params(), lab2, mx, yc, d2, 1)
+    assert fixed[3, 3] == lab[3, 3]
+    with pytest.raises(ValueError):
+        O.sp_relax(O.sp_params(), lab, 3, yc, d2, 1)          # labels >= max_label_id
+    with pytest.raises(ValueError):
+        O.sp_relax(O.sp_params(), lab, mx, yc, None, 1)        # disparity feature without its image
+    with pytest.raises(ValueError):
+        O.sp_relax(O.sp_params(compactness=-1.0), lab, mx, yc, d2, 1)
+
+
+def test_superpixel_plane_classify_matches_numpy():
+    rng = np.random.default_rng(14)
+    w, h = 61, 37
+    for n_prev in (0, 2):
+        labels, mx = O.sp_block_init(w, h, 7, 5)
+        d2 = rng.integers(-12, 30, (h, w, 2)).astype(np.int16)
+        d2[rng.random((h, w, 2)) < 0.2] = -32768
+        prev = [rng.integers(0, 3, (h, w)).astype(np.uint8) for _ in range(n_prev)]
+        flows = [(rng.integers(-40, 40, (h, w, 2)) * rng.integers(1, 64, (h, w, 2))).astype(np.int16) for _ in range(n_prev)]
+        params = (6, 22, -4, 6, 14, 1)
+        a = O.sp_classify(d2, labels, mx, params, prev, flows)
+        b = N.sp_classify(d2, labels, mx, params, prev, flows)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    # known answers (sp_planeseg.cu:145-160): UNKNOWN keeps ties, VERTICAL needs > UNKNOWN, HORIZONTAL needs > max(U, V)
+    labels = np.zeros((1, 6), np.uint16)
+    for vals, want in (((10, 10, 0, 0, -32768, -32768), 2), ((10, 10, 10, 0, 0, -32768), 0), ((10, 10, 0, 0, 0, -32768), 1),
+                       ((10, 10, 10, 0, 0, 0), 1), ((10, 0, -32768, -32768, -32768, -32768), 2)):
+        d2 = np.zeros((1, 6, 2), np.int16); d2[0, :, 0] = vals
+        _, pl = O.sp_classify(d2, labels, 1, (6, 22, -4, 6, 14, 1))
+        assert (pl == want).all(), (vals, want)
+
+
+def test_golden_superpixel_fixtures():
+    files = sorted(glob.glob(os.path.join(HERE, "golden", "sp_*.npz")))
+    assert files, "no superpixel golden fixtures committed"
+    for f in files:
+        z = np.load(f)
+        p = O.SpParams(*(float(z["p_" + k]) for k in ("direct", "diagonal", "compactness", "progressive", "image", "disparity")))
+        h, w = z["labels0"].shape
+        labels, mx = O.sp_block_init(w, h, int(z["block"]), int(z["block"]))
+        assert mx == int(z["max_label"])
+        for k in range(int(z["frames"])):
+            labels, _ = O.sp_relax(p, labels, mx, O.bgr2ycrcb(z[f"image{k}"]), z[f"deriv{k}"], int(z[f"iters{k}"]))
+            assert (labels == z[f"labels{k}"]).all(), (f, k)
+            uns, pl = O.sp_classify(z[f"deriv{k}"], labels, mx, tuple(int(v) for v in z["plane_params"]))
+            assert (uns == z[f"unsmoothed{k}"]).all() and (pl == z[f"planes{k}"]).all(), (f, k)
