@@ -31,6 +31,12 @@ class StereoDataElement : public DataElement {
     image_t right;
 };
 
+// src/datasource.cpp:18-28: the image the per-frame modules work on (left camera)
+inline image_t getReferenceImage(std::shared_ptr<DataElement> element) {
+    if (element->type == DataElementType::STEREO) return std::static_pointer_cast<StereoDataElement>(element)->left;
+    throw std::runtime_error("Unknown data element type");
+}
+
 class DataSource {
    public:
     explicit DataSource(Size imageSize) : imageSize(imageSize) {}

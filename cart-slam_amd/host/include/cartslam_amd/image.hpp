@@ -10,7 +10,7 @@
 namespace cart {
 
 // OpenCV type codes (depth + ((channels-1) << 3)), so `type()` checks read like the reference's (planeseg.cu:255)
-enum : int { CV_8UC1 = 0, CV_8UC3 = 16, CV_16SC1 = 3, CV_16SC2 = 11, CV_32SC1 = 4, CV_32SC2 = 12 };
+enum : int { CV_8UC1 = 0, CV_8UC3 = 16, CV_16UC1 = 2, CV_16SC1 = 3, CV_16SC2 = 11, CV_32SC1 = 4, CV_32SC2 = 12 };
 
 inline size_t elemSize(int type) {
     static const size_t depth_bytes[8] = {1, 1, 2, 2, 4, 4, 8, 2};  // CV_8U,8S,16U,16S,32S,32F,64F,16F

@@ -9,6 +9,7 @@
 #include <utility>
 
 #include "disparity.hpp"
+#include "superpixels.hpp"
 
 #define CARTSLAM_KEY_PLANES "planes"
 #define CARTSLAM_KEY_PLANES_UNSMOOTHED "planes_unsmoothed"
@@ -33,12 +34,14 @@ struct PlaneParameters {
 enum Plane { HORIZONTAL = 0, VERTICAL = 1, UNKNOWN = 2 };
 
 class DisparityPlaneSegmentationModule;
+class SuperPixelDisparityPlaneSegmentationModule;
 
 class PlaneParameterProvider {
    public:
     virtual ~PlaneParameterProvider() = default;
     PlaneParameters getPlaneParameters() const { return PlaneParameters(horizontalCenter, verticalCenter, horizontalRange, verticalRange); }
     friend class DisparityPlaneSegmentationModule;
+    friend class SuperPixelDisparityPlaneSegmentationModule;
 
    protected:
     PlaneParameterProvider(const int horizontalCenter = 0, const int verticalCenter = 0, const std::pair<int, int> horizontalRange = std::make_pair(0, 0),
@@ -87,6 +90,29 @@ class DisparityPlaneSegmentationModule : public SyncWrapperSystemModule {
     std::shared_ptr<PlaneParameterProvider> planeParameterProvider;
     std::shared_mutex derivativeHistogramMutex;
     int32_t *derivativeHistogram = nullptr;  // persistent 256-bin device histogram (planeseg.hpp:160-161)
+    std::mutex engineMutex;
+    std::shared_ptr<EngineHandle> engine;
+};
+
+// mirrors include/modules/planeseg.hpp:164-186 + src/modules/planeseg/sp_planeseg.cu:180-388: per-pixel classification of
+// the vertical directional derivative, optional temporal vote, majority vote per superpixel.
+class SuperPixelDisparityPlaneSegmentationModule : public SyncWrapperSystemModule {
+   public:
+    SuperPixelDisparityPlaneSegmentationModule(std::shared_ptr<PlaneParameterProvider> planeParameterProvider, const int updateInterval = 30, const int resetInterval = 10,
+                                               const bool useTemporalSmoothing = false,
+                                               const unsigned int temporalSmoothingDistance = CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT);
+    system_data_t runInternal(System &system, SystemRunData &data) override;
+
+   private:
+    void updatePlaneParameters(System &system, SystemRunData &data);  // sp_planeseg.cu:349-387
+
+    const bool useTemporalSmoothing;
+    const unsigned int temporalSmoothingDistance;
+    const int updateInterval;
+    const int resetInterval;
+    std::shared_ptr<PlaneParameterProvider> planeParameterProvider;
+    FrameOrder order;
+    std::vector<int32_t> derivativeHistogram;  // running total on the host (planeseg.hpp:185)
     std::mutex engineMutex;
     std::shared_ptr<EngineHandle> engine;
 };

@@ -4,6 +4,7 @@
 // the reference's "Unknown module type" error.
 #include "cartslam_amd/cartconfig.hpp"
 
+#include <cmath>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -13,6 +14,7 @@
 #include "cartslam_amd/modules/depth.hpp"
 #include "cartslam_amd/modules/disparity.hpp"
 #include "cartslam_amd/modules/planeseg.hpp"
+#include "cartslam_amd/modules/superpixels.hpp"
 
 #define CART_CONFIG_KEY_DATA_SOURCE "data_source"
 #define CART_CONFIG_KEY_MODULES "modules"
@@ -87,6 +89,18 @@ void applyModuleConfig(const Value &modulesConfig, std::shared_ptr<System> syste
                                                                 get(moduleConfig, "use_temporal_smoothing", false),
                                                                 (unsigned)get(moduleConfig, "temporal_smoothing_distance", CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT),
                                                                 get(moduleConfig, "label_components", false));
+        } else if (moduleType == "superpixels") {  // cartconfig.cpp:121-134
+            const double direct = get(moduleConfig, "direct_clique_cost", 0.5);
+            system->addModule<SuperPixelModule>(dataSource->getImageSize(), (unsigned)get(moduleConfig, "initial_iterations", 18), (unsigned)get(moduleConfig, "iterations", 6),
+                                                (unsigned)get(moduleConfig, "block_size", 12), (unsigned)get(moduleConfig, "reset_iterations", 64), direct,
+                                                get(moduleConfig, "diagonal_clique_cost", direct / std::sqrt(2.0)), get(moduleConfig, "compactness_weight", 0.1),
+                                                get(moduleConfig, "progressive_compactness_cost", 0.0), get(moduleConfig, "image_weight", 1.5),
+                                                get(moduleConfig, "disparity_weight", 1.0));
+        } else if (moduleType == "superpixel_disparity_planeseg") {  // cartconfig.cpp:212-220
+            const auto parameterProvider = readParameterProvider(moduleConfig.at("parameter_provider"));
+            system->addModule<SuperPixelDisparityPlaneSegmentationModule>(parameterProvider, get(moduleConfig, "update_interval", 30), get(moduleConfig, "reset_interval", 10),
+                                                                          get(moduleConfig, "use_temporal_smoothing", false),
+                                                                          (unsigned)get(moduleConfig, "temporal_smoothing_distance", CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT));
         } else if (moduleType == "optflow_file") {  // extension: replays flow fields from <sequence>/flow/%06d.bin
             system->addModule<OpticalFlowFileModule>();
         } else if (moduleType == "optflow") {

@@ -45,9 +45,15 @@ int main(int argc, char **argv) {
         }
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
-                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED};
+                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS};
             for (int id = 1; id <= frames; ++id) {
-                auto run = system->getRunById((uint32_t)id);
+                std::shared_ptr<cart::SystemRunData> run;
+                try { run = system->getRunById((uint32_t)id); } catch (const std::exception &) { continue; }  // evicted (retention ring)
+                if (run->hasData(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL)) {
+                    const cart::contour::label_t mx = *run->getData<cart::contour::label_t>(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL);
+                    std::ofstream o(dump + "/" + std::to_string(id) + "_" + CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL + ".bin", std::ios::binary);
+                    o.write(reinterpret_cast<const char *>(&mx), sizeof(mx));
+                }
                 for (const char *k : keys) {
                     if (!run->hasData(k)) continue;
                     auto img = run->getData<cart::image_t>(k);

@@ -2,12 +2,14 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
 #include "cartslam_amd/modules/depth.hpp"
 #include "cartslam_amd/modules/disparity.hpp"
 #include "cartslam_amd/modules/planeseg.hpp"
+#include "cartslam_amd/modules/superpixels.hpp"
 
 namespace cart {
 namespace {
@@ -227,6 +229,170 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
     }
     if (labelComponents) out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
     return out;
+}
+
+// ---------------------------------------------------------------- superpixels (superpixels.cu:19-118)
+FrameOrder::Turn::Turn(FrameOrder &o, uint32_t id) : order(o), id(id) {
+    std::unique_lock<std::mutex> lock(order.mutex);
+    while (order.next < id)
+        if (order.cv.wait_for(lock, std::chrono::seconds(5)) == std::cv_status::timeout && order.next < id) ++order.next;  // an earlier frame never came
+}
+FrameOrder::Turn::~Turn() {
+    {
+        std::lock_guard<std::mutex> lock(order.mutex);
+        if (order.next <= id) order.next = id + 1;
+    }
+    order.cv.notify_all();
+}
+
+SuperPixelModule::SuperPixelModule(const Size imageRes, const unsigned int initialIterations, const unsigned int iterations, const unsigned int blockSize,
+                                   const unsigned int resetIterations, const double directCliqueCost, const double diagonalCliqueCost, const double compactnessWeight,
+                                   const double progressiveCompactnessCost, const double imageWeight, const double disparityWeight)
+    : SyncWrapperSystemModule("SuperPixelDetect"), initialIterations(initialIterations), iterations(iterations), resetIterations(resetIterations),
+      blockSize(blockSize), requiresDisparityDerivative(disparityWeight > 0) {
+    if (blockSize < 1) throw std::invalid_argument("blockSize must be more than 1");                                        // superpixels.cu:37-39
+    if (directCliqueCost < 0) throw std::invalid_argument("directCliqueCost must be non-negative");                         // :41-43
+    if (compactnessWeight < 0 || imageWeight < 0 || disparityWeight < 0) throw std::invalid_argument("weight must be non-negative");  // :45-47
+    if (resetIterations < 1) throw std::invalid_argument("resetIterations must be at least 1");
+    if (disparityWeight > 0) this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY_DERIVATIVE));
+    this->providesData.push_back(CARTSLAM_KEY_SUPERPIXELS);
+    this->providesData.push_back(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL);
+    engine = std::make_shared<EngineHandle>(imageRes, paramsFor(imageRes, 0, 0, -1, 0, 0, 10, 120, 12));
+    cart_superpixel_params p{directCliqueCost, diagonalCliqueCost, compactnessWeight, progressiveCompactnessCost, imageWeight, disparityWeight};
+    if (cart_superpixels_create(engine->get(), &p, (int)blockSize, (int)blockSize, &contourRelaxation) != 0) engine->fail("cart_superpixels_create");
+}
+
+SuperPixelModule::~SuperPixelModule() { cart_superpixels_destroy(contourRelaxation); }
+
+system_data_t SuperPixelModule::runInternal(System &, SystemRunData &data) {
+    const image_t image = getReferenceImage(data.dataElement);  // the YCrCb conversion (superpixels.cu:81) happens inside cart_superpixels_relax
+    if (image.type() != CV_8UC3 && image.type() != CV_8UC1) throw std::runtime_error("SuperPixelModule requires CV_8UC1 or CV_8UC3 images");
+    std::shared_ptr<image_t> disparityDerivative;
+    if (this->requiresDisparityDerivative) {
+        disparityDerivative = data.getData<image_t>(CARTSLAM_KEY_DISPARITY_DERIVATIVE);
+        if (disparityDerivative->type() != CV_16SC2) throw std::runtime_error("Disparity derivative must be of type CV_16SC2");
+    }
+    const unsigned int numIterations = (data.id == 1 || data.id % this->resetIterations == 0) ? this->initialIterations : this->iterations;  // :92
+    auto relaxedLabelImage = std::make_shared<image_t>(image.rows, image.cols, CV_16UC1);
+    int maxLabelId = 0;
+    {
+        FrameOrder::Turn turn(order, data.id);  // the reference's mutex (:97-99), taken in frame order
+        ScopedStream stream;
+        if (data.id % this->resetIterations == 0)  // :104-112
+            if (cart_superpixels_reset(contourRelaxation, stream.s) != 0) engine->fail("cart_superpixels_reset");
+        if (cart_superpixels_relax(contourRelaxation, image.ptr<uint8_t>(), image.step, image.type() == CV_8UC3 ? 3 : 1,
+                                   disparityDerivative ? disparityDerivative->ptr<int16_t>() : nullptr, disparityDerivative ? disparityDerivative->step : 0,
+                                   (int)numIterations, relaxedLabelImage->ptr<uint16_t>(), relaxedLabelImage->step, stream.s) != 0)
+            engine->fail("cart_superpixels_relax");
+        maxLabelId = cart_superpixels_max_label(contourRelaxation);
+        stream.wait();
+    }
+    return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_SUPERPIXELS), std::shared_ptr<void>(relaxedLabelImage)),
+                             std::make_pair(std::string(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL), std::shared_ptr<void>(std::make_shared<contour::label_t>((contour::label_t)maxLabelId))));
+}
+
+// ---------------------------------------------------------------- superpixel plane labels (sp_planeseg.cu:180-388)
+SuperPixelDisparityPlaneSegmentationModule::SuperPixelDisparityPlaneSegmentationModule(std::shared_ptr<PlaneParameterProvider> provider, const int updateInterval,
+                                                                                       const int resetInterval, const bool useTemporalSmoothing,
+                                                                                       const unsigned int temporalSmoothingDistance)
+    : SyncWrapperSystemModule("SPPlaneSegmentation"), useTemporalSmoothing(useTemporalSmoothing), temporalSmoothingDistance(temporalSmoothingDistance),
+      updateInterval(updateInterval), resetInterval(resetInterval), planeParameterProvider(provider) {
+    if (useTemporalSmoothing && (temporalSmoothingDistance < 1 || temporalSmoothingDistance > CART_MAX_TEMPORAL))
+        throw std::runtime_error("temporal_smoothing_distance must be in [1, 8]");
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_SUPERPIXELS));  // sp_planeseg.cu:191-194
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL));
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY_DERIVATIVE));
+    this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM));
+    if (useTemporalSmoothing) {  // :196-205
+        this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_OPTFLOW));
+        for (size_t i = 1; i <= this->temporalSmoothingDistance; i++) {
+            this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_PLANES_UNSMOOTHED, -(int)i));
+            if ((i + 1) <= this->temporalSmoothingDistance) this->requiresData.push_back(module_dependency_t(CARTSLAM_KEY_OPTFLOW, -(int)i));
+        }
+    }
+    this->providesData.push_back(CARTSLAM_KEY_PLANES);
+    if (useTemporalSmoothing) this->providesData.push_back(CARTSLAM_KEY_PLANES_UNSMOOTHED);
+}
+
+system_data_t SuperPixelDisparityPlaneSegmentationModule::runInternal(System &system, SystemRunData &data) {
+    auto derivatives = data.getData<image_t>(CARTSLAM_KEY_DISPARITY_DERIVATIVE);
+    if (derivatives->empty()) return MODULE_NO_RETURN_VALUE;  // sp_planeseg.cu:223-226
+    if (derivatives->type() != CV_16SC2) throw std::runtime_error("Disparity must be of type CV_16SC2");  // :228-231
+    Size res; res.width = derivatives->cols; res.height = derivatives->rows;
+    std::shared_ptr<EngineHandle> eng;
+    {
+        std::lock_guard<std::mutex> lk(engineMutex);
+        if (!engine) engine = std::make_shared<EngineHandle>(res, paramsFor(res, 0, 0, -1, 0, 0, 10, 120, 12));
+        eng = engine;
+    }
+    cart_plane_params cp;
+    {
+        FrameOrder::Turn turn(order, data.id);
+        this->updatePlaneParameters(system, data);  // :237
+        const PlaneParameters pp = planeParameterProvider->getPlaneParameters();
+        cp = cart_plane_params{pp.horizontalRange.first, pp.horizontalRange.second, pp.verticalRange.first, pp.verticalRange.second, pp.horizontalCenter, pp.verticalCenter};
+    }
+    auto planes = std::make_shared<image_t>(derivatives->rows, derivatives->cols, CV_8UC1);
+    auto smoothed = std::make_shared<image_t>(derivatives->rows, derivatives->cols, CV_8UC1);
+    const uint8_t *prevPlanes[CART_MAX_TEMPORAL];
+    size_t prevSteps[CART_MAX_TEMPORAL];
+    const int16_t *flows[CART_MAX_TEMPORAL];
+    size_t flowSteps[CART_MAX_TEMPORAL];
+    int previousPlaneCount = 0;
+    std::vector<std::shared_ptr<image_t>> keepAlive;
+    if (this->useTemporalSmoothing && data.id > 1) {  // :250-300
+        auto optFlowCurr = data.getData<image_t>(CARTSLAM_KEY_OPTFLOW);
+        keepAlive.push_back(optFlowCurr);
+        flows[0] = optFlowCurr->ptr<int16_t>(); flowSteps[0] = optFlowCurr->step;
+        for (int i = 1; i <= (int)this->temporalSmoothingDistance; i++) {
+            if ((int64_t)data.id - i <= 0) break;
+            auto relativeRun = data.getRelativeRun((int8_t)-i);
+            std::shared_ptr<image_t> prev;
+            try { prev = relativeRun->getData<image_t>(CARTSLAM_KEY_PLANES_UNSMOOTHED); } catch (const std::exception &) { break; }  // :270-275
+            keepAlive.push_back(prev);
+            prevPlanes[previousPlaneCount] = prev->ptr<uint8_t>(); prevSteps[previousPlaneCount] = prev->step;
+            previousPlaneCount++;
+            if (relativeRun->id > 1 && previousPlaneCount < (int)this->temporalSmoothingDistance) {
+                std::shared_ptr<image_t> optFlow;
+                try { optFlow = relativeRun->getData<image_t>(CARTSLAM_KEY_OPTFLOW); } catch (const std::exception &) { break; }  // :289-294
+                keepAlive.push_back(optFlow);
+                flows[previousPlaneCount] = optFlow->ptr<int16_t>(); flowSteps[previousPlaneCount] = optFlow->step;
+            }
+        }
+    }
+    auto labels = data.getData<image_t>(CARTSLAM_KEY_SUPERPIXELS);
+    const contour::label_t maxLabel = *data.getData<contour::label_t>(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL);
+    if (labels->type() != CV_16UC1) throw std::runtime_error("Superpixels must be of type CV_16UC1");
+    if (((size_t)maxLabel + 1) * 3 * sizeof(uint16_t) > 32768)  // the reference's shared-memory bound (:317-321), kept as the accepted range
+        throw std::runtime_error("Shared memory size exceeds maximum. Reduce image size or increase block size.");
+    ScopedStream stream;
+    if (cart_superpixel_plane_classify(eng->get(), derivatives->ptr<int16_t>(), derivatives->step, labels->ptr<uint16_t>(), labels->step, (int)maxLabel, &cp,
+                                       previousPlaneCount, prevPlanes, prevSteps, flows, flowSteps, planes->ptr<uint8_t>(), planes->step, smoothed->ptr<uint8_t>(),
+                                       smoothed->step, stream.s) != 0)
+        eng->fail("cart_superpixel_plane_classify");
+    stream.wait();
+    return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(smoothed)),  // :341-343: both keys, always
+                             std::make_pair(std::string(CARTSLAM_KEY_PLANES_UNSMOOTHED), std::shared_ptr<void>(planes)));
+}
+
+void SuperPixelDisparityPlaneSegmentationModule::updatePlaneParameters(System &system, SystemRunData &data) {
+    // channel 0 (vertical derivative) of the frame's CV_32SC2 1x256 histogram (sp_planeseg.cu:350-356)
+    auto histImage = data.getData<image_t>(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM);
+    std::vector<uint8_t> raw = histImage->downloadTight();
+    const int32_t *two = reinterpret_cast<const int32_t *>(raw.data());
+    std::vector<int32_t> histogram(256);
+    for (int i = 0; i < 256; ++i) histogram[i] = two[2 * i];
+    if (this->derivativeHistogram.empty()) {
+        this->derivativeHistogram.assign(256, 0);  // :360-361: the first frame starts the running total at ZERO and is itself not added
+    } else {
+        for (int i = 0; i < 256; ++i) this->derivativeHistogram[i] += histogram[i];  // :363-365
+        histogram = this->derivativeHistogram;
+    }
+    if ((int)(data.id % (uint32_t)(this->updateInterval * this->resetInterval)) == 1) this->derivativeHistogram.assign(256, 0);  // :368-371
+    if ((int)(data.id % (uint32_t)this->updateInterval) != 1) return;  // :374-376
+    this->planeParameterProvider->updatePlaneParameters(system, data, histogram);
+    system.insertGlobalData(CARTSLAM_KEY_PLANE_PARAMETERS, std::make_shared<PlaneParameters>(this->planeParameterProvider->getPlaneParameters()));
+    system.insertGlobalData(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HIST, std::make_shared<std::vector<int32_t>>(histogram));
 }
 
 system_data_t OpticalFlowFileModule::runInternal(System &system, SystemRunData &data) {

@@ -59,8 +59,12 @@ def test_exe_exists():
 def test_config_errors_read_like_the_reference(tmp_path):
     tmp = str(tmp_path)
     src, _ = make_dataset(tmp, 1, 64, 32)
-    r = run_exe(src, [{"type": "superpixels"}], tmp)  # a module type outside the hot path
-    assert r.returncode != 0 and "Unknown module type superpixels." in r.stderr  # cartconfig.cpp:226
+    r = run_exe(src, [{"type": "features"}], tmp)  # a module type outside the hot path
+    assert r.returncode != 0 and "Unknown module type features." in r.stderr  # cartconfig.cpp:226
+    r = run_exe(src, [{"type": "superpixels", "block_size": 0}], tmp)
+    assert r.returncode != 0 and "blockSize must be more than 1" in r.stderr  # superpixels.cu:37-39
+    r = run_exe(src, [{"type": "superpixels", "image_weight": -1.0}], tmp)
+    assert r.returncode != 0 and "weight must be non-negative" in r.stderr  # superpixels.cu:45-47
     r = run_exe(src, {"type": "disparity"}, tmp)
     assert r.returncode != 0 and "Modules configuration is not an array." in r.stderr  # cartconfig.cpp:107-109
     r = run_exe(src, [{"type": "disparity_planeseg", "parameter_provider": {"type": "static", "horizontal_range_min": 1}}], tmp)
@@ -248,3 +252,68 @@ def test_temporal_smoothing_frame_loop(tmp_path):
     # the reference's own provider of "optflow" is NVIDIA hardware: asking for it must fail loudly
     r = run_exe(src, [{"type": "optflow"}], tmp)
     assert r.returncode != 0 and "not supported" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("temporal", [False, True])
+def test_superpixel_planeseg_frame_loop(tmp_path, temporal):
+    """The reference's plane-segmentation configuration (config/modules/kitti-planeseg.json: superpixels, disparity,
+    disparity_derivative, superpixel_disparity_planeseg with the histogram_peak provider; "optflow" replaced by the file
+    replay) through the frame loop with up to 12 frames in flight: the stateful modules take frames in id order."""
+    tmp = str(tmp_path)
+    w, h, n, bs, reset = 320, 96, 7, 8, 4
+    src, frames = make_dataset(tmp, n, w, h, channels=3)
+    flows = []
+    if temporal:
+        fdir = os.path.join(tmp, "dataset", "sequences", "00", "flow")
+        os.makedirs(fdir)
+        rng = np.random.default_rng(18)
+        for f in range(n):
+            fl = (rng.integers(-6, 7, (h, w, 2)) * 32 + rng.integers(0, 32, (h, w, 2))).astype(np.int16)
+            fl.tofile(os.path.join(fdir, "%06d.bin" % f)); flows.append(fl)
+    os.makedirs(os.path.join(tmp, "dump"))
+    modules = [{"type": "superpixels", "initial_iterations": 5, "iterations": 2, "block_size": bs, "reset_iterations": reset},
+               {"type": "disparity", "num_disparities": 64, "smoothing_radius": 2, "smoothing_iterations": 1},
+               {"type": "disparity_derivative"},
+               {"type": "superpixel_disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}, "update_interval": 2, "reset_interval": 2,
+                "use_temporal_smoothing": temporal},
+               {"type": "disparity_planeseg_visualization", "show_histogram": False}]
+    if temporal:
+        modules.insert(1, {"type": "optflow_file"})
+    r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump")))
+    assert r.returncode == 0, r.stderr
+    sp = O.sp_params()  # JSON factory defaults (cartconfig.cpp:128-133)
+    labels, mx = O.sp_block_init(w, h, bs, bs)
+    running, params, unsm = None, (0, 0, 0, 0, 0, 0), []
+    for f, (l, rr) in enumerate(frames):
+        fid = f + 1
+        ed = O.disparity_module(l, rr, 64, 4, 4, radius=2, iterations=1)
+        d2, dh = O.directional_derivative(ed)
+        # SuperPixelModule::runInternal (superpixels.cu:92-115)
+        iters = 5 if (fid == 1 or fid % reset == 0) else 2
+        if fid % reset == 0:
+            labels, mx = O.sp_block_init(w, h, bs, bs)
+        labels, _ = O.sp_relax(sp, labels, mx, O.bgr2ycrcb(l), d2, iters)
+        assert (load(tmp, fid, "superpixels", np.uint16, (h, w)) == labels).all(), f"superpixels frame {fid}"
+        assert int(np.fromfile(os.path.join(tmp, "dump", f"{fid}_superpixels_max_label.bin"), np.uint16)[0]) == mx
+        # SuperPixelDisparityPlaneSegmentationModule::updatePlaneParameters (sp_planeseg.cu:349-387)
+        hist = dh[:, 0].astype(np.int64)
+        if running is None:
+            running = np.zeros(256, np.int64)
+        else:
+            running += hist
+            hist = running.copy()
+        if fid % 4 == 1:
+            running[:] = 0
+        if fid % 2 == 1:
+            _, params = O.histogram_peak_params(hist.astype(np.int32), params)
+        prev, fl = [], []
+        if temporal and fid > 1:
+            k = min(3, fid - 1)
+            prev = [unsm[f - i] for i in range(1, k + 1)]
+            fl = [flows[f - i] for i in range(0, k)]
+        eu, ep = O.sp_classify(d2, labels, mx, params, prev, fl)
+        unsm.append(eu)
+        assert (load(tmp, fid, "planes_unsmoothed", np.uint8, (h, w)) == eu).all(), f"unsmoothed frame {fid}"
+        assert (load(tmp, fid, "planes", np.uint8, (h, w)) == ep).all(), f"planes frame {fid}"
+    assert len({tuple(np.unique(load(tmp, i + 1, "planes", np.uint8, (h, w)))) for i in range(n)} - {(2,)}) >= 1  # not all UNKNOWN
