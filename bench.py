@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--disparities", type=int, default=128)
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
@@ -116,8 +117,8 @@ def main():
 
     w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
-                 max_inflight=B, device_id=dev_index)
-    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True)
+                 max_inflight=B if args.no_overlap else 2 * B, device_id=dev_index)
+    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=not args.no_overlap)
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     n_distinct = min(B, 4)
     ls, rs = synth.make_batch(n_distinct, w, h, D, 4, first_frame=rank * n_distinct)

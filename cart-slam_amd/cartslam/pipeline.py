@@ -61,7 +61,7 @@ class StereoPipeline:
     (PlaneParameterSchedule + cart_find_plane_params), which is what the reference's module does per frame."""
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
-                 with_ccl=True, group=None, device_schedule=True):
+                 with_ccl=True, group=None, device_schedule=True, overlap=False):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
@@ -76,14 +76,34 @@ class StereoPipeline:
             self.rank = torch.distributed.get_rank(group)
         self.next_id = 1
         self._hist = None
+        # overlap=True: the plane stages of batch i run on a side stream while the main stream already computes the
+        # disparity of batch i+1 (the plane stages are short, latency-bound launches that leave the GPU mostly idle).
+        # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
+        # order.  Outputs other than "disparity" are then produced on `self.side`: synchronise (or wait for
+        # out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
+        self.side = torch.cuda.Stream() if overlap else None
 
     def process_batch(self, left, right):
+        if self.side is None:
+            return self._process_batch(left, right)
+        import torch
+        main = torch.cuda.current_stream()
+        disp = self.engine.compute_disparity(left, right)
+        self.side.wait_stream(main)
+        disp.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            out = self._process_batch(left, right, disp)
+            out["done"] = self.side.record_event()
+        return out
+
+    def _process_batch(self, left, right, disp=None):
         """left/right: uint8 [n,h,w(,3)] on the GPU: this rank's n frames of a global batch of
         n*world frames (interleaved ids).  -> dict(disparity, planes, ids, n_components, params)."""
         import torch
         eng = self.engine
         n = left.shape[0]
-        disp = eng.compute_disparity(left, right)
+        if disp is None:
+            disp = eng.compute_disparity(left, right)
         if self._hist is None or self._hist.shape[0] != n:
             self._hist = torch.empty((n, 256), dtype=torch.int32, device=left.device)
         self._hist.zero_()

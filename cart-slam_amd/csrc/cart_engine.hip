@@ -91,13 +91,22 @@ int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
     std::unique_lock<std::mutex> lk(e->mu);
     int s0 = -1;
     for (;;) {
+        // First fit, preferring a range whose slots were last used on THIS stream (or never): reusing another stream's
+        // slots costs an event wait that serialises two pipelined streams for no reason.
         const int total = (int)e->slots.size();
+        int fallback = -1;
         for (int i = 0; i + n <= total && s0 < 0; ++i) {
-            bool ok = true;
-            for (int k = 0; k < n; ++k)
-                if (e->slots[i + k].busy) { ok = false; i += k; break; }
-            if (ok) s0 = i;
+            bool ok = true, same = true;
+            for (int k = 0; k < n; ++k) {
+                const Slot &sl = e->slots[i + k];
+                if (sl.busy) { ok = false; i += k; break; }
+                same &= !sl.used || sl.last_stream == stream;
+            }
+            if (!ok) continue;
+            if (same) s0 = i;
+            else if (fallback < 0) fallback = i;
         }
+        if (s0 < 0) s0 = fallback;
         if (s0 >= 0) break;
         e->cv.wait(lk);
     }

@@ -321,21 +321,23 @@ def test_batched_pipeline_matches_frame_by_frame_oracle(torch_cuda):
     from cartslam.pipeline import StereoPipeline
     w, h, D, P, n = 256, 96, 64, 8, 7
     ui, ri = 3, 2
-    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=4)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=8)
     ls, rs = synth.make_batch(n, w, h, D, 4, seed=99)
     for device_schedule in (True, False):
         _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule)
+    # two-stream pipelining of consecutive batches (plane stages of batch i on a side stream under the disparity of i+1)
+    _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, True, overlap=True)
     eng.close()
 
 
-def _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule):
+def _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule, overlap=False):
     from cartslam.pipeline import StereoPipeline
     pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True,
-                          device_schedule=device_schedule)
-    outs = []
-    for a in range(0, n, 4):  # batches of 4, then 3
-        o = pipe.process_batch(dev(torch, ls[a:a + 4]), dev(torch, rs[a:a + 4]))
-        outs.append({k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in o.items()})
+                          device_schedule=device_schedule, overlap=overlap)
+    inputs = [(dev(torch, ls[a:a + 4]), dev(torch, rs[a:a + 4])) for a in range(0, n, 4)]  # batches of 4, then 3
+    raw = [pipe.process_batch(l, r) for l, r in inputs]  # enqueued back to back, nothing read in between
+    torch.cuda.synchronize()
+    outs = [{k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in o.items()} for o in raw]
     disp = np.concatenate([o["disparity"] for o in outs]); planes = np.concatenate([o["planes"] for o in outs])
     ids = np.concatenate([o["ids"] for o in outs]); ncomp = np.concatenate([o["n_components"] for o in outs])
     cum = np.zeros(256, np.int64)
