@@ -10,7 +10,7 @@
 // MI355X design: the reference compacts border pixels into a global list and reads its length back to the host in
 // every iteration (one device->host round trip per iteration) and keeps per-label statistics behind device-side
 // virtual calls.  Here one iteration is two launches and no host round trip:
-//   sp_relax_kernel   one 64x16 tile per workgroup; labels + halo in LDS; border pixels are compacted into an LDS
+//   sp_relax_kernel   one 32x16 tile per workgroup; labels + halo in LDS; border pixels are compacted into an LDS
 //                     list so that all 256 lanes work on border pixels; every border pixel evaluates its candidate
 //                     labels against the label statistics of the iteration start (Jacobi, oracle S13), writes the
 //                     next label image and accumulates the statistics DELTA of its own move with 64-bit integer
@@ -26,7 +26,12 @@ namespace cart_amd {
 
 namespace {
 
-constexpr int kTileW = 64, kTileH = 16;
+#ifndef CART_SP_TILE_W
+#define CART_SP_TILE_W 32
+#define CART_SP_TILE_H 16
+#endif
+constexpr int kTileW = CART_SP_TILE_W, kTileH = CART_SP_TILE_H;   // 32x16: ~1000 workgroups at 1242x375 (64x16 left half the CUs with one workgroup)
+static_assert(kTileW * kTileH % 256 == 0 && 256 % kTileW == 0 && kTileW <= 256 && kTileH <= 255, "tile must be a multiple of the 256-thread block");
 constexpr uint16_t kOob = 0xFFFFu;
 
 __device__ __forceinline__ double sp_log(double x) {  // oracle S13
@@ -170,8 +175,8 @@ __global__ __launch_bounds__(256) void sp_relax_kernel(SpRelaxArgs a) {
     __syncthreads();
     // pixels whose in-image neighbourhood holds a single label keep it (they would have one candidate only)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int lx = tid & 63, ly = (tid >> 6) + 4 * k;
+    for (int k = 0; k < kTileW * kTileH / 256; ++k) {
+        const int lx = tid % kTileW, ly = tid / kTileW + (256 / kTileW) * k;
         const int x = x0 + lx, y = y0 + ly;
         if (x < a.w && y < a.h) {
             const uint16_t c = tile[ly + 1][lx + 1];

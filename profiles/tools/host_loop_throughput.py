@@ -9,6 +9,9 @@ tmp = tempfile.mkdtemp(dir="/tmp")
 d = os.path.join(tmp, "ds", "sequences", "00"); os.makedirs(d + "/image_2"); os.makedirs(d + "/image_3")
 n = 240
 base = [synth.make_pair(1242, 375, 128, 4, frame=f) for f in range(4)]
+SP = [{"type": "superpixels", "initial_iterations": 24, "iterations": 8, "block_size": 12, "reset_iterations": 64},
+      {"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1}, {"type": "disparity_derivative"}, {"type": "depth"},
+      {"type": "superpixel_disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]  # config/modules/kitti-planeseg.json minus optflow / GUI
 for f in range(n):
     l, r, _ = base[f % 4]
     for cam, img in ((2, l), (3, r)):
@@ -18,7 +21,8 @@ json.dump({"type": "kitti", "path": os.path.join(tmp, "ds"), "sequence": 0}, ope
 for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "num_disparities": 128, "paths": 8, "smoothing_radius": 2, "smoothing_iterations": 1},
                                                         {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
                    ("reference default (D=256, 4 paths) + planeseg", [{"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1},
-                                                                      {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}])):
+                                                                      {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
+                   ("kitti-planeseg.json (superpixels 24/8 sweeps, D=256 4 paths, derivative, depth, superpixel planeseg)", SP)):
     json.dump(mods, open(tmp + "/mod.json", "w"))
     exe = os.path.join(ROOT, "cart-slam_amd", "build", "cart_slam_amd")
     t0 = time.time()
@@ -36,7 +40,9 @@ for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "nu
     fr.sort(key=lambda x: int(x[1]))
     inits = [int(x[2]) for x in fr]
     print("   frame init spacing ms:", [b - a for a, b in zip(inits[:16], inits[1:17])], " frame durations us:", [int(x[6]) for x in fr[:12]])
-    ps = [int(x[6]) for x in rows if x[0] == "PlaneSegmentation"]
-    print("   median PlaneSegmentation us:", sorted(ps)[len(ps) // 2])
+    for mod in ("PlaneSegmentation", "SuperPixelDetect", "SPPlaneSegmentation", "ImageDisparityDerivative", "Depth"):
+        ps = [int(x[6]) for x in rows if x[0] == mod]
+        if ps:
+            print(f"   median {mod} us:", sorted(ps)[len(ps) // 2])
     ds = [int(x[6]) for x in rows if x[0] == "DataSource"]
     print("   median DataSource (read + decode + upload) us:", sorted(ds)[len(ds) // 2])
