@@ -152,7 +152,9 @@ def main():
         value = pairs / elapsed
         fpl = min(B, 16)  # frames per launch: the engine runs batches as sub-batches of <= 16 frames (cart_engine.hip)
         agg_ms = stages.get("aggregate", 0.0)  # mean duration of ONE aggregate launch (fpl frames)
-        agg_bytes = alg_bytes_aggregate(w, h, D, P) * fpl
+        # D=256 batches run the WTA fused with the "up" direction (cart_engine.hip): the aggregate launch then covers P-1 paths
+        fused = D >= 256 and fpl >= 4 and os.environ.get("CART_FUSED_WTA", "1") != "0"
+        agg_bytes = alg_bytes_aggregate(w, h, D, P - 1 if fused else P) * fpl
         achieved = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")

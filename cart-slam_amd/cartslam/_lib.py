@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "build", "libcart_engine.so")
+LIB_PATH = os.environ.get("CART_ENGINE_LIB") or os.path.join(os.path.dirname(_HERE), "build", "libcart_engine.so")  # override: timing experiments
 
 
 class EngineParams(C.Structure):

@@ -65,8 +65,11 @@ struct cart_engine {
     uint32_t *right_pk = nullptr;
     int16_t *tmp_a = nullptr, *tmp_b = nullptr;  // tight s16 planes (interpolate ping-pong)
     int32_t *ccl_work = nullptr;
+    uint32_t *rv_partial = nullptr; // [max_inflight][wta_fused_partial_elems], allocated by the first fused batch
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
+    AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
+    int fused_min_frames = 1 << 30; // batches of at least this many frames take the fused WTA
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
@@ -144,8 +147,7 @@ void release(const Lease &l) {
     e->cv.notify_all();
 }
 
-void build_agg_args(cart_engine *e) {
-    AggArgs &a = e->agg;
+void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     const Geometry &g = e->g;
     a.g = g;
     // launch order: the long serial scans (horizontal, W steps) get the lowest block ids so they
@@ -154,8 +156,8 @@ void build_agg_args(cart_engine *e) {
     static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
     // diagnostic only (timing experiments; results are wrong when directions are dropped):
     // CART_DEBUG_DIRMASK = bit mask over the launch-order directions to keep
-    unsigned mask = 0xffu;
-    if (const char *m = std::getenv("CART_DEBUG_DIRMASK")) mask = (unsigned)std::strtoul(m, nullptr, 0);
+    unsigned mask = keep;
+    if (const char *m = std::getenv("CART_DEBUG_DIRMASK")) mask &= (unsigned)std::strtoul(m, nullptr, 0);
     int blk = 0, nd = 0;
     const int lpb = agg_lines_per_block(g.D);
     for (int i = 0; i < g.P; ++i) {
@@ -275,7 +277,15 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
             cart_engine_destroy(e);
             return fail("hipEventCreate failed");
         }
-    build_agg_args(e);
+    build_agg_args(e, e->agg, 0xffu);
+    build_agg_args(e, e->agg_fused, 0xffu & ~(1u << 3));  // launch-order slot 3 = {0,-1} = "up" (slab kFusedUpPath)
+    // Fused WTA (the "up" direction computed inside the WTA sweep, 1/P less slab traffic): measured on MI355X at
+    // 1242x375, batch 16 (profiles/tools/disparity_only.py): D=256 -9 % (4 paths) / -15 % (8 paths) per batch, D=128
+    // even, D=64 +4..6 % -- so it is the default for D=256 batches only.  CART_FUSED_WTA=1 forces it for every D (from
+    // 8 frames up), =0 disables it; CART_FUSED_MIN_FRAMES overrides the batch size from which it is used.
+    e->fused_min_frames = g.D >= 256 ? 4 : 1 << 30;
+    if (const char *f = std::getenv("CART_FUSED_WTA")) e->fused_min_frames = std::atoi(f) == 0 ? 1 << 30 : std::min(e->fused_min_frames, 8);
+    if (const char *f = std::getenv("CART_FUSED_MIN_FRAMES")) e->fused_min_frames = std::max(1, std::atoi(f));
     *out = e;
     return 0;
 }
@@ -283,7 +293,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
@@ -364,6 +374,10 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
     if (out_frame_stride & 1) return fail("out_frame_stride must be even");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(e->params.device_id));
+    if (std::min(n_frames, e->chunk_frames) >= e->fused_min_frames) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->rv_partial) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
+    }
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
@@ -394,11 +408,13 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
         ImageBatch rb{right + (size_t)f0 * right_frame_stride, right_step, right_frame_stride};
         launch_census(lb, rb, channels, n, gl, gr, cl, cr, rpk, g, st);
         STAGE("aggregate");
-        AggArgs a = e->agg;
+        const bool fused = n >= e->fused_min_frames && e->rv_partial;
+        AggArgs a = fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
         STAGE("wta");
-        launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
+        if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
+        else launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
         STAGE("post");
         if (!smooth) {
             launch_post(wl, rpk, gl, o, out_step, out_frame_stride, g, n, st);

@@ -60,6 +60,11 @@ int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is 
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s);
+// WTA fused with the "up" direction (slab kFusedUpPath is never read: the aggregate launch may skip that direction)
+constexpr int kFusedUpPath = 1;
+size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer
+void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
+                      uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s);
 void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, int16_t *out,
                  size_t out_step, size_t out_frame_stride, const Geometry &g, int n_frames, hipStream_t s);
 

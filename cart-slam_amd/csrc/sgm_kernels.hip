@@ -222,7 +222,7 @@ __device__ __forceinline__ void agg_xor(const CensusRegs &c, uint32_t (&xr)[16])
     for (int k = 0; k < 16; ++k) xr[k] = c.fl ^ c.r[k];
 }
 
-template <int LPP>
+template <int LPP, bool STORE = true>
 __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&xr)[16], uint32_t sel_lo,
                                          uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2, CART_GLOBAL uint8_t *po) {
     // Issue cost on gfx950 (profiles/tools/valu_rate.hip): v_add/v_sub/v_xor ~2.7 clk, packed ops / v_perm / v_bcnt /
@@ -249,19 +249,22 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
     // u8 slab bytes of the lane's 16 disparities in the kernel's native order (one v_perm per register pair): dword q
     // holds d0 + {2q, 2q+8, 2q+1, 2q+9}; the WTA widens byte pairs straight back into the same split-halves registers
     // (slab byte layout: see kSlabChunkOrder in engine_internal.h)
-    uint4 o;
-    o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
-    o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
+    if constexpr (STORE) {
+        uint4 o;
+        o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
+        o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
 #ifdef CART_ABLATE_STORE  // timing experiment only: keep the bytes live, skip the slab store
-    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
-    (void)po;
+        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+        (void)po;
 #else
-    {   // write-once streaming data: non-temporal so the slabs do not evict the census planes from L2
+        // write-once streaming data: non-temporal so the slabs do not evict the census planes from L2
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         const v4u q = {o.x, o.y, o.z, o.w};
         __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);
-    }
 #endif
+    } else {
+        (void)po;  // the fused WTA consumes the new costs from the registers
+    }
     // min over the pixel's D disparities, replicated into both halves
     uint32_t x = pk_min(pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3])), pk_min(pk_min(n[4], n[5]), pk_min(n[6], n[7])));
     x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
@@ -644,6 +647,259 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
         case 128: hipLaunchKernelGGL(wta_kernel<8>, grid, block, lds, s, slabs, wta_l, right_pk, g, uniq); break;
         default: hipLaunchKernelGGL(wta_kernel<16>, grid, block, lds, s, slabs, wta_l, right_pk, g, uniq); break;
     }
+}
+
+// ------------------------------------------------------------------ winner takes all, fused with the "up" direction
+// For batches the slab of ONE direction never has to exist: this kernel sweeps every column bottom-up, computes the
+// "up" path costs on the fly (the same agg_step, registers only), adds the other P-1 slabs and runs the WTA of the row
+// it is on.  That removes 1/P of the slab writes and reads (the launch sequence is HBM bound: aggregate writes at
+// ~4.6 TB/s, WTA reads at ~6 TB/s).  Block = 4 waves = 4*P adjacent columns, one image row per step; per step
+//   * cost recurrence of the block's columns (wave-private right-census window through LDS like aggregate_kernel),
+//   * S = L_up + sum of the stored slabs (16-byte non-temporal loads, prefetched one step ahead),
+//   * left disparity exactly as wta_kernel (packed keys, integer uniqueness threshold, sub-pixel from the LDS tile),
+//   * right view: every lane min-reduces its 16 (S<<16|d) keys into a block-local LDS array indexed by p = x - d
+//     (ds_min_u32); the block's NR = 4P + D - 1 minima of the row go to a per-block partial buffer with plain stores
+//     and rv_merge_kernel takes the min over the <= ceil((D-1)/4P)+1 blocks that cover a right pixel (global atomics
+//     straight from this kernel cost 0.16 ms per 16-frame launch, the partial buffer is 2 % of the slab traffic).
+// The LDS tile is double buffered (one barrier per step); left disparities and right-view minima are buffered in LDS
+// for 16 rows and written out in one burst, so the row loop itself holds loads only and the prefetch of row y-1
+// stays in flight while row y is processed.
+#ifndef CART_FUSED_ABLATE
+#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store
+#endif
+struct FusedArgs {
+    const uint32_t *cen_l, *cen_r;
+    const uint8_t *slabs;
+    uint16_t *wta_l;
+    uint32_t *partial;   // [frame][y][block][NR + 1] right-view minima of every block (last entry: unused sink)
+    Geometry g;
+    float uniq;
+};
+constexpr int kUpPath = 1;   // slab index of the direction computed here and never stored (oracle order: down, up, ...)
+
+template <int LPP, int NP>
+struct FusedRegs {
+    uint32_t win[Win<LPP>::NLD];
+    uint32_t fl;
+    uint32_t sv[NP - 1][4];
+};
+
+// NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
+// can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
+template <int LPP, int NP>
+__global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
+    using WN = Win<LPP>;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr int P = WN::P, D = WN::D, COLS = 4 * P, NR = COLS + D - 1, NRP = NR + 1;
+    __shared__ uint32_t s_win[4][WN::BUF];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tile[2][COLS * D];
+    constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores
+    __shared__ uint32_t s_rmin[RB][NRP];
+    __shared__ uint16_t s_out[RB][COLS];
+    const Geometry &g = a.g;
+    const int nblk = (g.w + COLS - 1) / COLS;
+    const int frame = blockIdx.x / nblk, blk = blockIdx.x - frame * nblk, x0 = blk * COLS;
+    const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
+    const int gl = lane % LPP, pg = lane / LPP, d0 = gl * 16;
+    const int xl = wid * P + pg, x = x0 + xl;       // column inside the block / the image
+    const int xw0 = x0 + wid * P;                   // wave's first column (uniform)
+    const bool valid = x < g.w;
+    const uint32_t p1p1 = (uint32_t)g.p1 * 0x10001u, p2p2 = (uint32_t)g.p2 * 0x10001u;
+    const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
+    const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
+
+    for (int i = threadIdx.x; i < RB * NRP; i += 256) (&s_rmin[0][0])[i] = 0xffffffffu;
+
+    // right-census window of the wave (see aggregate_kernel): cooperative load offsets + this lane's read slots
+    unsigned goff[WN::NLD];
+#pragma unroll
+    for (int i = 0; i < WN::NLD; ++i) {
+        const int l = 64 * i + lane;
+        goff[i] = (unsigned)(16 * (l / 20) + min(l % 20, 15)) * 4u;
+    }
+    const int wl = pg + D - 16 - d0;
+    const int base_slot = wl + 4 * (wl >> 4);
+    int xslot[P - 1];
+#pragma unroll
+    for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
+    uint32_t *wbuf = &s_win[wid][0];
+
+    // row-0 bases; columns past the image compute on padding / clamped slab columns and never write
+    const ptrdiff_t cen0 = (ptrdiff_t)frame * (ptrdiff_t)g.census_elems + g.cpadl + xw0;
+    const uint32_t *pw0 = a.cen_r + uniform(cen0 - g.min_disp - (D - 1));
+    const uint32_t *pl0 = a.cen_l + uniform(cen0);
+    unsigned lo_l = (unsigned)pg * 4u;
+    const int xc = min(x, g.w - 1);
+    const uint8_t *ps0 = a.slabs + (size_t)frame * g.P * g.slab_bytes + (size_t)xc * D + d0;
+
+    auto load_row = [&](int y, FusedRegs<LPP, NP> &r) {
+        const uint32_t *pw = pw0 + (ptrdiff_t)y * g.cpitch;
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) r.win[i] = ld_u32(pw, goff[i]);
+        r.fl = ld_u32(pl0 + (ptrdiff_t)y * g.cpitch, lo_l);
+        const uint8_t *ps = ps0 + (size_t)y * g.w * D;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p == kUpPath) continue;
+            const int k = p < kUpPath ? p : p - 1;  // compile-time after unrolling
+            const v4u v = (CART_FUSED_ABLATE & 4) ? v4u{0x01010101u * (uint32_t)(y & 7), 0x02020202u, 0x03030303u, 0x04040404u}
+                                                  : __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ps + (size_t)p * g.slab_bytes));
+            r.sv[k][0] = v.x; r.sv[k][1] = v.y; r.sv[k][2] = v.z; r.sv[k][3] = v.w;
+        }
+    };
+
+    uint32_t st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = 0;
+    uint32_t mm = 0;
+
+    auto step = [&](int t, int y, const FusedRegs<LPP, NP> &r) {
+        // ---- "up" path costs of row y (oracle S3/S4), registers only
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) wbuf[64 * i + lane] = r.win[i];
+        CensusRegs c;
+        c.fl = r.fl;
+        win_read<LPP>(wbuf, base_slot, xslot, c.r);
+        uint32_t xr[16];
+        agg_xor(c, xr);
+        agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
+        // ---- S in natural adjacent pairs: sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q])
+        uint32_t sm[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sm[q] = perm(st[2 * q + 1], st[2 * q], 0x05040100u);
+            sm[4 + q] = perm(st[2 * q + 1], st[2 * q], 0x07060302u);
+        }
+#pragma unroll
+        for (int k = 0; k < NP - 1; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sm[q] += r.sv[k][q] & 0x00ff00ffu;
+                sm[4 + q] += perm(0u, r.sv[k][q], 0x0c030c01u);
+            }
+        }
+        const int b = t & 1;
+        uint16_t *tile = &s_tile[b][0];
+        v4u *dst = reinterpret_cast<v4u *>(tile + xl * D + d0);
+        dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
+        dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
+        // ---- left view: argmin + uniqueness (same arithmetic as wta_kernel)
+        uint32_t key[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
+            key[k] = __builtin_bit_cast(uint32_t, kk);
+        }
+        uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
+        m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
+        uint32_t pk = ((m >> 4) << 16) | (uint32_t)(d0 + (int)(m & 15u));
+        pk = group_allmin<LPP>(pk);
+        const uint32_t T = uniq_threshold(pk >> 16, a.uniq);
+        const uint32_t tt = T * 0x10001u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
+        const uint32_t tot = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
+        // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d
+        if (valid && !(CART_FUSED_ABLATE & 2)) {
+            uint32_t *rm = &s_rmin[t % RB][xl + D - 1 - d0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
+                atomicMin(rm - da, (sm[q] << 16) | (uint32_t)(d0 + da));
+                atomicMin(rm - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+            }
+        }
+        __syncthreads();
+        // ---- sub-pixel (the pixel's first lane) into the LDS output rows
+        if (gl == 0) {
+            const int bd = (int)(pk & 0xffffu), bc = (int)(pk >> 16);
+            const uint16_t *srow = tile + xl * D;
+            const int l = bd > 0 ? srow[bd - 1] : 0x7fff, rr = bd < D - 1 ? srow[bd + 1] : 0x7fff;
+            const int Ti = (int)T;
+            const int tot_nbr = max(Ti - bc, 0) + max(Ti - l, 0) + max(Ti - rr, 0);
+            uint32_t out = kWtaInvalid;
+            if ((int)tot == tot_nbr) {
+                int subp = bd * 16;
+                if (bd > 0 && bd < D - 1) {
+                    const int num = l - rr, den = l - 2 * bc + rr;
+                    if (den != 0) subp += (num * 16 + den) / (2 * den);
+                }
+                out = (uint32_t)subp & 0xffffu;
+            }
+            s_out[t % RB][xl] = (uint16_t)out;
+        }
+        // ---- every RB rows (and after the last one): burst the buffered rows out.  Stores inside the row loop sit
+        // between the prefetch loads in vmcnt's in-order retirement and cost ~0.3 ms per launch when issued every row.
+        if (t % RB == RB - 1 || y == 0) {
+            const int nrows = t % RB + 1, ytop = y;   // buffered rows: LDS row r holds image row ytop + (nrows - 1 - r)
+            __syncthreads();
+            for (int i = threadIdx.x; i < nrows * COLS; i += 256) {
+                const int r = i / COLS, c = i - r * COLS;
+                if (x0 + c < g.w && !(CART_FUSED_ABLATE & 16))
+                    a.wta_l[(size_t)frame * g.npx + (size_t)(ytop + nrows - 1 - r) * g.w + x0 + c] = s_out[r][c];
+            }
+            for (int i = threadIdx.x; i < nrows * NRP; i += 256) {
+                const int r = i / NRP, c = i - r * NRP;
+                const uint32_t v = s_rmin[r][c];
+                s_rmin[r][c] = 0xffffffffu;
+                if (!(CART_FUSED_ABLATE & 8))
+                    a.partial[(((size_t)frame * g.h + (ytop + nrows - 1 - r)) * nblk + blk) * NRP + c] = v;
+            }
+            __syncthreads();
+        }
+    };
+
+    __syncthreads();
+    FusedRegs<LPP, NP> ra, rb;
+    load_row(g.h - 1, ra);
+    for (int t = 0; t < g.h; t += 2) {
+        const int y = g.h - 1 - t;
+        load_row(max(y - 1, 0), rb);
+        step(t, y, ra);
+        load_row(max(y - 2, 0), ra);
+        if (y - 1 >= 0) step(t + 1, y - 1, rb);
+    }
+}
+
+// right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p
+__global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk) {
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
+    if (p >= w || y >= h) return;
+    const int nrp = cols + D;
+    const int b0 = p / cols, b1 = min((p + D - 1) / cols, nblk - 1);
+    const uint32_t *row = partial + ((size_t)frame * h + y) * nblk * nrp;
+    uint32_t best = 0xffffffffu;
+    for (int b = b0; b <= b1; ++b) best = min(best, row[(size_t)b * nrp + (p - (b * cols - (D - 1)))]);
+    right_pk[((size_t)frame * h + y) * w + p] = best;
+}
+
+size_t wta_fused_partial_elems(const Geometry &g) {
+    const int cols = 4 * (64 / (g.D / 16));
+    return (size_t)g.h * ((g.w + cols - 1) / cols) * (cols + g.D);
+}
+
+void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
+                      uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s) {
+    FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq};
+    const int cols = 4 * (64 / (g.D / 16));
+    const int nblk = (g.w + cols - 1) / cols;
+    dim3 grid(nblk * n_frames), block(256);
+    if (g.P == 4) {
+        switch (g.D) {
+            case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 4>), grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 4>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((wta_fused_kernel<16, 4>), grid, block, 0, s, a); break;
+        }
+    } else {
+        switch (g.D) {
+            case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 8>), grid, block, 0, s, a); break;
+            case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 8>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((wta_fused_kernel<16, 8>), grid, block, 0, s, a); break;
+        }
+    }
+    hipLaunchKernelGGL(rv_merge_kernel, dim3((g.w + 63) / 64, (g.h + 3) / 4, n_frames), dim3(256), 0, s, (const uint32_t *)partial, right_pk,
+                       g.w, g.h, g.D, cols, nblk);
 }
 
 // ------------------------------------------------------------------ median x2 + LR check + range fix

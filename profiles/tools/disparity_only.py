@@ -1,0 +1,19 @@
+"""Stage times of cart_compute_disparity_batch alone (no plane stages, one stream): batch 16, 1242x375, D=128, 8 paths."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "cart-slam_amd")]
+import numpy as np, torch
+from cartslam import Engine, synth
+w, h, D, P, B = 1242, 375, int(os.environ.get("D", 128)), int(os.environ.get("P", 8)), int(os.environ.get("B", 16))
+eng = Engine(w, h, num_disparities=D, paths=P, smoothing_radius=2, smoothing_iterations=1, max_inflight=B)
+ls, rs = synth.make_batch(4, w, h, D, 4)
+L = torch.from_numpy(np.concatenate([ls] * (B // 4))).cuda(); R = torch.from_numpy(np.concatenate([rs] * (B // 4))).cuda()
+for _ in range(4):
+    eng.compute_disparity(L, R)
+torch.cuda.synchronize()
+eng.set_timing(True)
+for _ in range(30):
+    eng.compute_disparity(L, R)
+torch.cuda.synchronize()
+st, n = eng.collect_timing()
+print(os.environ.get("TAG", ""), {k: round(v, 4) for k, v in st.items()}, "sum", round(sum(st.values()), 4))

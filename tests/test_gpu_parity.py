@@ -511,3 +511,58 @@ def test_concurrent_host_threads_one_engine(torch_cuda):
     for i in range(8):
         assert (results[i] == expected[i]).all(), f"thread {i}"
     eng.close()
+
+
+FUSED_CASES = [
+    # w, h, D, P, min_disp, frames
+    (160, 96, 64, 4, 4, 2),
+    (173, 67, 64, 8, 0, 3),       # ragged: the last block holds invalid columns, odd height
+    (200, 120, 128, 8, 4, 2),
+    (330, 50, 256, 8, 9, 2),
+    (64, 16, 64, 8, 4, 1),        # narrower than D, one block
+    (97, 131, 128, 4, 64, 2),
+    (257, 33, 128, 8, 4, 9),      # a wave of entirely invalid columns (257 = 8*32 + 1), batch above the default threshold
+]
+
+
+@pytest.mark.parametrize("w,h,D,P,md,n", FUSED_CASES)
+def test_fused_wta_path(torch_cuda, w, h, D, P, md, n, monkeypatch):
+    """Batches take the WTA kernel that computes the "up" direction on the fly (its slab is never written): the
+    remaining slabs, both WTA maps and the disparity must still equal the oracle's, for every frame of the batch."""
+    torch = torch_cuda
+    monkeypatch.setenv("CART_FUSED_MIN_FRAMES", "1")  # read at engine creation
+    eng = make_engine(w, h, D, P, md, inflight=max(n, 2))
+    ls, rs = synth.make_batch(n, w, h, D, md, seed=4000 + w)
+    disp = eng.compute_disparity(dev(torch, ls), dev(torch, rs)).cpu().numpy()
+    for f in range(n):
+        cl, cr = O.census(ls[f]), O.census(rs[f])
+        S = np.zeros((h, w, D), np.uint16)
+        for i in range(P):
+            dx, dy = O.path_dir(i)
+            L = O.aggregate_path(cl, cr, D, md, 10, 120, dx, dy)
+            if (dx, dy) != (0, -1):
+                assert (eng.debug_read(16 + i, frame_slot=f) == L).all(), f"frame {f} path {i}"
+            S += L
+        wl, wr = O.wta(S, 12)
+        assert (eng.debug_read(32, frame_slot=f) == wl).all(), f"frame {f} wta left: {int((eng.debug_read(32, frame_slot=f) != wl).sum())} differ"
+        assert (eng.debug_read(33, frame_slot=f) == wr).all(), f"frame {f} wta right"
+        exp = O.lr_check_range(O.median3x3(wl), O.median3x3(wr), ls[f], md)
+        assert (disp[f] == exp).all(), f"frame {f} disparity"
+    eng.close()
+
+
+def test_fused_and_two_kernel_paths_agree_at_full_size(torch_cuda, monkeypatch):
+    torch = torch_cuda
+    w, h, D, P, n = 1242, 375, 128, 8, 8
+    ls, rs = synth.make_batch(2, w, h, D, 4, seed=31)
+    L = dev(torch, np.concatenate([ls] * 4)); R = dev(torch, np.concatenate([rs] * 4))
+    monkeypatch.setenv("CART_FUSED_WTA", "0")
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)
+    a = eng.compute_disparity(L, R).cpu().numpy()
+    eng.close()
+    monkeypatch.setenv("CART_FUSED_WTA", "1")
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)  # forced: fused from 8 frames up (default for D=256 only)
+    b = eng.compute_disparity(L, R).cpu().numpy()
+    eng.close()
+    assert (a == b).all() and (a[0] == a[2]).all() and (a[0] != a[1]).any()
+    assert (a[0] == O.disparity_module(ls[0], rs[0], D, P, 4, radius=2, iterations=1)).all()
