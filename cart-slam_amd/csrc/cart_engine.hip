@@ -281,9 +281,13 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     build_agg_args(e, e->agg_fused, 0xffu & ~(1u << 3));  // launch-order slot 3 = {0,-1} = "up" (slab kFusedUpPath)
     // Fused WTA (the "up" direction computed inside the WTA sweep, 1/P less slab traffic): measured on MI355X at
     // 1242x375, batch 16 (profiles/tools/disparity_only.py): D=256 -9 % (4 paths) / -15 % (8 paths) per batch, D=128
-    // even, D=64 +4..6 % -- so it is the default for D=256 batches only.  CART_FUSED_WTA=1 forces it for every D (from
+    // even, D=64 +4..6 %; D=256 batches of 4 frames: +5 % at 1242x375, -11 % at 1920x1080 -- so it is the default for
+    // D=256 batches that give the sweep enough workgroups.  CART_FUSED_WTA=1 forces it for every D (from
     // 8 frames up), =0 disables it; CART_FUSED_MIN_FRAMES overrides the batch size from which it is used.
-    e->fused_min_frames = g.D >= 256 ? 4 : 1 << 30;
+    {   // from ~450 workgroups (16 columns each at D=256) the sweep fills the chip: 6 frames at 1242 px, 4 at 1920 px
+        const int nblk = (g.w + 15) / 16;
+        e->fused_min_frames = g.D >= 256 ? std::max(2, (448 + nblk - 1) / nblk) : 1 << 30;
+    }
     if (const char *f = std::getenv("CART_FUSED_WTA")) e->fused_min_frames = std::atoi(f) == 0 ? 1 << 30 : std::min(e->fused_min_frames, 8);
     if (const char *f = std::getenv("CART_FUSED_MIN_FRAMES")) e->fused_min_frames = std::max(1, std::atoi(f));
     *out = e;

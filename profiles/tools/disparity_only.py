@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [os.path.join(ROOT, "cart-slam_amd")]
 import numpy as np, torch
 from cartslam import Engine, synth
-w, h, D, P, B = 1242, 375, int(os.environ.get("D", 128)), int(os.environ.get("P", 8)), int(os.environ.get("B", 16))
+w, h, D, P, B = int(os.environ.get("W", 1242)), int(os.environ.get("H", 375)), int(os.environ.get("D", 128)), int(os.environ.get("P", 8)), int(os.environ.get("B", 16))
 eng = Engine(w, h, num_disparities=D, paths=P, smoothing_radius=2, smoothing_iterations=1, max_inflight=B)
 ls, rs = synth.make_batch(4, w, h, D, 4)
 L = torch.from_numpy(np.concatenate([ls] * (B // 4))).cuda(); R = torch.from_numpy(np.concatenate([rs] * (B // 4))).cuda()
