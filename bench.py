@@ -153,7 +153,8 @@ def main():
         fpl = min(B, 16)  # frames per launch: the engine runs batches as sub-batches of <= 16 frames (cart_engine.hip)
         agg_ms = stages.get("aggregate", 0.0)  # mean duration of ONE aggregate launch (fpl frames)
         # D=256 batches run the WTA fused with the "up" direction (cart_engine.hip): the aggregate launch then covers P-1 paths
-        fused = D >= 256 and fpl >= 4 and os.environ.get("CART_FUSED_WTA", "1") != "0"
+        nblk16 = (w + 15) // 16
+        fused = D >= 256 and fpl >= max(2, (448 + nblk16 - 1) // nblk16) and os.environ.get("CART_FUSED_WTA", "1") != "0"
         agg_bytes = alg_bytes_aggregate(w, h, D, P - 1 if fused else P) * fpl
         achieved = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else 0.0
         traffic = None
