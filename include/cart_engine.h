@@ -230,7 +230,8 @@ int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left,
 enum {
     CART_DBG_GRAY_L = 0, CART_DBG_GRAY_R = 1,     /* u8  [h][w]              */
     CART_DBG_CENSUS_L = 2, CART_DBG_CENSUS_R = 3, /* u32 [h][w]              */
-    CART_DBG_PATH0 = 16,                          /* +r: u8 [h][w][D], r<paths */
+    CART_DBG_PATH0 = 16,                          /* +r: u8 [h][w][D], r<paths; path 1 ("up") is not materialised by
+                                                     batches that take the fused WTA (D=256) */
     CART_DBG_WTA_L = 32, CART_DBG_WTA_R = 33      /* u16 [h][w]              */
 };
 int cart_debug_read(cart_engine *engine, int frame_slot, int what, void *host_dst, size_t bytes);

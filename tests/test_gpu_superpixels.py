@@ -235,3 +235,67 @@ def test_golden_superpixel_fixtures(torch_cuda):
                                                     tuple(int(v) for v in z["plane_params"]))
             assert (uns.cpu().numpy() == z[f"unsmoothed{k}"]).all() and (pl.cpu().numpy() == z[f"planes{k}"]).all(), (f, k)
         sp.close(); eng.close()
+
+
+def test_streams_threads_and_lifecycle(torch_cuda):
+    """One object driven alternately from two streams without host synchronisation (calls are ordered by the object's
+    event), two objects driven concurrently from two host threads, and create/destroy cycles that must not leak."""
+    import threading
+    torch = torch_cuda
+    w, h, bs = 160, 90, 9
+    rng = np.random.default_rng(44)
+    eng = geometry_engine(w, h)
+    scenes = [random_scene(rng, w, h) for _ in range(4)]
+    dscenes = [(dev(torch, b), dev(torch, d)) for b, d in scenes]
+    want, mx = O.sp_block_init(w, h, bs, bs)
+    exp = []
+    for b, d in scenes:
+        want, _ = O.sp_relax(O.sp_params(), want, mx, O.bgr2ycrcb(b), d, 2)
+        exp.append(want)
+    # (1) alternate streams, no sync in between
+    sp = make_sp(eng, bs, {})
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = []
+    for k, (b, d) in enumerate(dscenes):
+        with torch.cuda.stream(streams[k % 2]):
+            outs.append(sp.relax(b, d, 2))
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert (labels_np(outs[k]) == exp[k]).all(), k
+    sp.close()
+    # (2) two objects, two host threads
+    results, errors = {}, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            obj = make_sp(eng, bs, {})
+            with torch.cuda.stream(s):
+                got = [obj.relax(b, d, 2) for b, d in dscenes]
+            s.synchronize()
+            results[i] = [labels_np(g) for g in got]
+            obj.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for i in range(2):
+        for k in range(4):
+            assert (results[i][k] == exp[k]).all(), (i, k)
+    # (3) lifecycle
+    def cycle(n):
+        for _ in range(n):
+            o = make_sp(eng, bs, {})
+            o.relax(dscenes[0][0], dscenes[0][1], 1)
+            o.close()
+        torch.cuda.synchronize()
+    cycle(3)
+    free0 = torch.cuda.mem_get_info()[0]
+    cycle(20)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"leak: {(free0 - free1) >> 20} MiB over 20 create/destroy cycles"
+    eng.close()
