@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--disparities", type=int, default=128)
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
@@ -142,6 +143,40 @@ def main():
     elapsed = time.perf_counter() - t0
     stages, ncalls = eng.collect_timing()
     eng.set_timing(False)
+    pcie = None
+    if world == 1 and not args.no_pcie:
+        # Informational (never `value`): the same step when the caller hands over HOST buffers -- H2D of the 16 pairs
+        # from pinned memory, the hot path, D2H of disparity + planes into pinned memory, copies on their own stream.
+        hl, hr = left.cpu().pin_memory(), right.cpu().pin_memory()
+        hd = torch.empty((B, h, w), dtype=torch.int16).pin_memory()
+        hp = torch.empty((B, h, w), dtype=torch.uint8).pin_memory()
+        h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+        bufs = [(torch.empty_like(left), torch.empty_like(right)) for _ in range(3)]
+        consumed = [None] * 3
+        def pcie_step(i):
+            dl, dr = bufs[i % 3]
+            if consumed[i % 3] is not None:
+                h2d.wait_event(consumed[i % 3])  # the batch that last read this input buffer has finished its disparity
+            with torch.cuda.stream(h2d):
+                dl.copy_(hl, non_blocking=True); dr.copy_(hr, non_blocking=True)
+                up = h2d.record_event()
+            torch.cuda.current_stream().wait_event(up)
+            o = pipe.process_batch(dl, dr)
+            consumed[i % 3] = torch.cuda.current_stream().record_event()
+            d2h.wait_event(o["done"]) if "done" in o else d2h.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(d2h):
+                hd.copy_(o["disparity"], non_blocking=True); hp.copy_(o["planes"], non_blocking=True)
+                o["disparity"].record_stream(d2h); o["planes"].record_stream(d2h)
+        for i in range(2):
+            pcie_step(i)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        n_pcie = max(4, min(args.steps, 20))
+        for i in range(n_pcie):
+            pcie_step(i)
+        torch.cuda.synchronize()
+        pcie = {"pairs_per_s": round(B * n_pcie / (time.perf_counter() - tp), 1), "steps": n_pcie,
+                "moved_per_pair": "2 x gray H2D (pinned), s16 disparity + u8 planes D2H"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +219,8 @@ def main():
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
         }
+        if pcie:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, D, P)
         print(json.dumps(out), flush=True)
