@@ -566,3 +566,45 @@ def test_fused_and_two_kernel_paths_agree_at_full_size(torch_cuda, monkeypatch):
     eng.close()
     assert (a == b).all() and (a[0] == a[2]).all() and (a[0] != a[1]).any()
     assert (a[0] == O.disparity_module(ls[0], rs[0], D, P, 4, radius=2, iterations=1)).all()
+
+
+def test_tile_loaders_on_the_reference_ramp(torch_cuda):
+    """The only "test vector" in the reference tree is the 1280x720 coordinate ramp v = y*1280 + x that its debug kernel
+    feeds to copyToShared (src/utils/sanity_check.cu:57-65): every element identifies its own position, so a
+    mis-addressed tile or halo load shows up.  Every kernel of the build that stages tiles or reads neighbourhoods runs
+    on ramp-derived inputs of that size against the oracle."""
+    torch = torch_cuda
+    w, h = 1280, 720
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = (yy * 1280 + xx).astype(np.int64)
+    # disparity-like s16 image: position-unique inside every 1100-wide window, valid for the post filter (64 < v < 1280)
+    disp = (ramp % 1100 + 80).astype(np.int16)
+    disp[(ramp % 97) == 0] = -32768
+    eng = make_engine(w, h, 64, 4, 4, inflight=1)
+    d = dev(torch, disp)
+    for r, it in ((2, 1), (4, 2)):
+        got = eng.interpolate(d.clone(), r, it, 64, 1280).cpu().numpy()
+        assert (got == O.interpolate(disp, r, it, 64, 1280)).all(), (r, it)
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    pd = eng.plane_derivative_hist(d, hist)
+    epd, eh = O.plane_derivative(disp)
+    assert (pd.cpu().numpy() == epd).all() and (hist.cpu().numpy() == eh).all()
+    dd, dh = eng.disparity_derivative(d)
+    edd, edh = O.directional_derivative(disp)
+    assert (dd.cpu().numpy() == edd).all() and (dh.cpu().numpy() == edh).all()
+    # census tile + halo: gray = a position hash (the ramp itself is monotone along x: every comparison would be equal)
+    gray = (((ramp * 2654435761) >> 13) & 255).astype(np.uint8)
+    eng.compute_disparity(dev(torch, gray), dev(torch, np.roll(gray, -7, axis=1)))
+    assert (eng.debug_read(2) == O.census(gray)).all()
+    assert (eng.debug_read(3) == O.census(np.roll(gray, -7, axis=1))).all()
+    eng.close()
+    # superpixel label tile + halo
+    from cartslam import Superpixels
+    geo = make_engine(w, h, 0, 0)
+    sp = Superpixels(geo, block_size=16)
+    bgr = np.stack([gray, np.roll(gray, 3, axis=0), np.roll(gray, 5, axis=1)], axis=-1)
+    got = sp.relax(dev(torch, bgr), dev(torch, edd), 2).cpu().numpy().view(np.uint16)
+    lab, mx = O.sp_block_init(w, h, 16, 16)
+    want, changes = O.sp_relax(O.sp_params(), lab, mx, O.bgr2ycrcb(bgr), edd, 2)
+    assert changes > 0 and (got == want).all()
+    sp.close(); geo.close()
