@@ -6,8 +6,8 @@ import numpy as np, torch
 from cartslam import Engine, synth
 w, h, D, P, B = int(os.environ.get("W", 1242)), int(os.environ.get("H", 375)), int(os.environ.get("D", 128)), int(os.environ.get("P", 8)), int(os.environ.get("B", 16))
 eng = Engine(w, h, num_disparities=D, paths=P, smoothing_radius=2, smoothing_iterations=1, max_inflight=B)
-ls, rs = synth.make_batch(4, w, h, D, 4)
-L = torch.from_numpy(np.concatenate([ls] * (B // 4))).cuda(); R = torch.from_numpy(np.concatenate([rs] * (B // 4))).cuda()
+ls, rs = synth.make_batch(max(1, min(4, B)), w, h, D, 4)
+L = torch.from_numpy(np.concatenate([ls] * max(1, B // 4))).cuda(); R = torch.from_numpy(np.concatenate([rs] * max(1, B // 4))).cuda()
 for _ in range(4):
     eng.compute_disparity(L, R)
 torch.cuda.synchronize()
