@@ -6,6 +6,8 @@
 // 3x3 medians, left-right check and range fix.  Written for wave64: a pixel is owned by D/16
 // adjacent lanes (16 disparities per lane, packed u16 pairs), neighbour exchange and the min over
 // D are DPP ops inside a 16-lane row; see the comments at each kernel.
+#include <type_traits>
+
 #include "engine_internal.h"
 
 namespace cart_amd {
@@ -665,8 +667,14 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 // for 16 rows and written out in one burst, so the row loop itself holds loads only and the prefetch of row y-1
 // stays in flight while row y is processed.
 #ifndef CART_FUSED_ABLATE
-#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store
+#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view
 #endif
+// Waves per block of the fused sweep.  The sweep has frames*W/(64/LPP) waves in total (2484 at 16 x 1242, D=128: 2.4 per
+// SIMD), so small blocks spread them evenly over the CUs: with 4-wave blocks a quarter of the CUs carried 3 blocks, the
+// rest 2, and the launch took the time of 3.  D=256 keeps 4 waves: its blocks would otherwise be 8 columns wide and the
+// right-view partial rows (columns + D - 1 entries per block and row) would grow to 17 % of the slab traffic.
+constexpr int fused_waves(int lpp) { return lpp >= 16 ? 4 : 2; }
+
 struct FusedArgs {
     const uint32_t *cen_l, *cen_r;
     const uint8_t *slabs;
@@ -681,21 +689,23 @@ template <int LPP, int NP>
 struct FusedRegs {
     uint32_t win[Win<LPP>::NLD];
     uint32_t fl;
-    uint32_t sv[NP - 1][4];
+    uint32_t sv[2][NP - 1][4];   // two rows of slab bytes in flight (see the Little's-law note at the kernel)
 };
 
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
 template <int LPP, int NP>
-__global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
+__global__ __launch_bounds__(64 * fused_waves(LPP), 12 / fused_waves(LPP)) void wta_fused_kernel(FusedArgs a) {  // 3 waves per SIMD
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    constexpr int P = WN::P, D = WN::D, COLS = 4 * P, NR = COLS + D - 1, NRP = NR + 1;
-    __shared__ uint32_t s_win[4][WN::BUF];
+    constexpr int WPB = fused_waves(LPP), NT = 64 * WPB;
+    constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
+    __shared__ uint32_t s_win[WPB][WN::BUF];
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[2][COLS * D];
     constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores
     __shared__ uint32_t s_rmin[RB][NRP];
-    __shared__ uint16_t s_out[RB][COLS];
+    __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
+    __shared__ uint16_t s_thr[2048];             // uniqueness threshold by best cost (sums are <= 8 * 255)
     const Geometry &g = a.g;
     const int nblk = (g.w + COLS - 1) / COLS;
     const int frame = blockIdx.x / nblk, blk = blockIdx.x - frame * nblk, x0 = blk * COLS;
@@ -708,7 +718,8 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
     const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
     const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
 
-    for (int i = threadIdx.x; i < RB * NRP; i += 256) (&s_rmin[0][0])[i] = 0xffffffffu;
+    for (int i = threadIdx.x; i < RB * NRP; i += NT) (&s_rmin[0][0])[i] = 0xffffffffu;
+    for (int i = threadIdx.x; i < 2048; i += NT) s_thr[i] = (uint16_t)uniq_threshold((uint32_t)i, a.uniq);
 
     // right-census window of the wave (see aggregate_kernel): cooperative load offsets + this lane's read slots
     unsigned goff[WN::NLD];
@@ -724,27 +735,38 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
     for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
     uint32_t *wbuf = &s_win[wid][0];
 
-    // row-0 bases; columns past the image compute on padding / clamped slab columns and never write
+    // row-0 bases (wave-uniform, kept in SGPRs) + constant per-lane byte offsets: every load is "scalar base + VGPR
+    // offset".  Columns past the image compute on padding / the clamped last slab column and never write.
     const ptrdiff_t cen0 = (ptrdiff_t)frame * (ptrdiff_t)g.census_elems + g.cpadl + xw0;
     const uint32_t *pw0 = a.cen_r + uniform(cen0 - g.min_disp - (D - 1));
     const uint32_t *pl0 = a.cen_l + uniform(cen0);
     unsigned lo_l = (unsigned)pg * 4u;
-    const int xc = min(x, g.w - 1);
-    const uint8_t *ps0 = a.slabs + (size_t)frame * g.P * g.slab_bytes + (size_t)xc * D + d0;
+    const int xbase = min(xw0, g.w - 1), xc = min(x, g.w - 1);   // xbase <= xc
+    const uint8_t *ps0 = a.slabs + uniform((ptrdiff_t)frame * g.P * (ptrdiff_t)g.slab_bytes + (ptrdiff_t)xbase * D);
+    unsigned lo_s = (unsigned)((xc - xbase) * D + d0);
+    const ptrdiff_t row_bytes = (ptrdiff_t)g.w * D;
 
-    auto load_row = [&](int y, FusedRegs<LPP, NP> &r) {
+    // Census registers: one set, re-loaded for row y-1 as soon as row y has consumed it.  Slab registers: two sets, each
+    // re-loaded for row y-2 when row y has consumed it -- the sweep has only frames*W/P waves (2484 at 16 x 1242, D=128)
+    // with 7 KB of slab bytes per wave and row, and one row in flight (17 MB) capped the reads at 4.7 TB/s.
+    FusedRegs<LPP, NP> r;
+    auto load_census_row = [&](int y) {
         const uint32_t *pw = pw0 + (ptrdiff_t)y * g.cpitch;
 #pragma unroll
         for (int i = 0; i < WN::NLD; ++i) r.win[i] = ld_u32(pw, goff[i]);
         r.fl = ld_u32(pl0 + (ptrdiff_t)y * g.cpitch, lo_l);
-        const uint8_t *ps = ps0 + (size_t)y * g.w * D;
+    };
+    auto load_slab_row = [&](int y, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        const uint8_t *ps = ps0 + (ptrdiff_t)((CART_FUSED_ABLATE & 32) ? (y & 1) : y) * row_bytes;  // 32: all rows from two L2-resident ones
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (p == kUpPath) continue;
             const int k = p < kUpPath ? p : p - 1;  // compile-time after unrolling
-            const v4u v = (CART_FUSED_ABLATE & 4) ? v4u{0x01010101u * (uint32_t)(y & 7), 0x02020202u, 0x03030303u, 0x04040404u}
-                                                  : __builtin_nontemporal_load(reinterpret_cast<const v4u *>(ps + (size_t)p * g.slab_bytes));
-            r.sv[k][0] = v.x; r.sv[k][1] = v.y; r.sv[k][2] = v.z; r.sv[k][3] = v.w;
+            const v4u v = (CART_FUSED_ABLATE & 4)
+                              ? v4u{0x01010101u * (uint32_t)(y & 7), 0x02020202u, 0x03030303u, 0x04040404u}
+                              : __builtin_nontemporal_load((const CART_GLOBAL v4u *)((const CART_GLOBAL char *)sgpr(ps + (ptrdiff_t)p * (ptrdiff_t)g.slab_bytes) + pin_v(lo_s)));
+            r.sv[SET][k][0] = v.x; r.sv[SET][k][1] = v.y; r.sv[SET][k][2] = v.z; r.sv[SET][k][3] = v.w;
         }
     };
 
@@ -753,7 +775,8 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
     for (int i = 0; i < 8; ++i) st[i] = 0;
     uint32_t mm = 0;
 
-    auto step = [&](int t, int y, const FusedRegs<LPP, NP> &r) {
+    auto step = [&](int t, int lr, int y, auto set_c) {   // t: step (tile parity), lr: LDS output row, y: image row
+        constexpr int SET = decltype(set_c)::value;
         // ---- "up" path costs of row y (oracle S3/S4), registers only
 #pragma unroll
         for (int i = 0; i < WN::NLD; ++i) wbuf[64 * i + lane] = r.win[i];
@@ -762,6 +785,9 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
         win_read<LPP>(wbuf, base_slot, xslot, c.r);
         uint32_t xr[16];
         agg_xor(c, xr);
+        __builtin_amdgcn_sched_barrier(0);
+        load_census_row(max(y - 1, 0));        // the census registers are free again: prefetch the next row
+        __builtin_amdgcn_sched_barrier(0);
         agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
         // ---- S in natural adjacent pairs: sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q])
         uint32_t sm[8];
@@ -774,10 +800,13 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
         for (int k = 0; k < NP - 1; ++k) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                sm[q] += r.sv[k][q] & 0x00ff00ffu;
-                sm[4 + q] += perm(0u, r.sv[k][q], 0x0c030c01u);
+                sm[q] += r.sv[SET][k][q] & 0x00ff00ffu;
+                sm[4 + q] += perm(0u, r.sv[SET][k][q], 0x0c030c01u);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
+        __builtin_amdgcn_sched_barrier(0);
         const int b = t & 1;
         uint16_t *tile = &s_tile[b][0];
         v4u *dst = reinterpret_cast<v4u *>(tile + xl * D + d0);
@@ -794,15 +823,15 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
         m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
         uint32_t pk = ((m >> 4) << 16) | (uint32_t)(d0 + (int)(m & 15u));
         pk = group_allmin<LPP>(pk);
-        const uint32_t T = uniq_threshold(pk >> 16, a.uniq);
+        const uint32_t T = s_thr[pk >> 16];  // = uniq_threshold(best cost): the float search runs once per block, not per row
         const uint32_t tt = T * 0x10001u;
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
         const uint32_t tot = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d
-        if (valid && !(CART_FUSED_ABLATE & 2)) {
-            uint32_t *rm = &s_rmin[t % RB][xl + D - 1 - d0];
+        if (valid && !(CART_FUSED_ABLATE & (2 | 64))) {
+            uint32_t *rm = &s_rmin[lr][xl + D - 1 - d0];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
@@ -811,15 +840,29 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
             }
         }
         __syncthreads();
-        // ---- sub-pixel (the pixel's first lane) into the LDS output rows
+        // ---- the pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
+        // deferred to the burst below, where all lanes work on it
         if (gl == 0) {
             const int bd = (int)(pk & 0xffffu), bc = (int)(pk >> 16);
             const uint16_t *srow = tile + xl * D;
             const int l = bd > 0 ? srow[bd - 1] : 0x7fff, rr = bd < D - 1 ? srow[bd + 1] : 0x7fff;
             const int Ti = (int)T;
             const int tot_nbr = max(Ti - bc, 0) + max(Ti - l, 0) + max(Ti - rr, 0);
+            const uint32_t unique = (int)tot == tot_nbr ? 1u : 0u;
+            s_rec[lr][xl] = make_uint2((uint32_t)bd | (unique << 8) | ((uint32_t)bc << 9), (uint32_t)l | ((uint32_t)rr << 16));
+        }
+    };
+
+    // Burst of the buffered rows (LDS row r holds image row ytop + nrows-1-r).  Stores inside the row loop would sit
+    // between the prefetch loads in vmcnt's in-order retirement; the row loop itself is branch-free and holds loads only.
+    auto flush = [&](int nrows, int ytop) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nrows * COLS; i += NT) {
+            const int r = i / COLS, c = i - r * COLS;
+            const uint2 rec = s_rec[r][c];
+            const int bd = (int)(rec.x & 0xffu), bc = (int)(rec.x >> 9), l = (int)(rec.y & 0xffffu), rr = (int)(rec.y >> 16);
             uint32_t out = kWtaInvalid;
-            if ((int)tot == tot_nbr) {
+            if (rec.x & 0x100u) {  // oracle S5 sub-pixel
                 int subp = bd * 16;
                 if (bd > 0 && bd < D - 1) {
                     const int num = l - rr, den = l - 2 * bc + rr;
@@ -827,38 +870,38 @@ __global__ __launch_bounds__(256) void wta_fused_kernel(FusedArgs a) {
                 }
                 out = (uint32_t)subp & 0xffffu;
             }
-            s_out[t % RB][xl] = (uint16_t)out;
+            if (x0 + c < g.w && !(CART_FUSED_ABLATE & 16))
+                a.wta_l[(size_t)frame * g.npx + (size_t)(ytop + nrows - 1 - r) * g.w + x0 + c] = (uint16_t)out;
         }
-        // ---- every RB rows (and after the last one): burst the buffered rows out.  Stores inside the row loop sit
-        // between the prefetch loads in vmcnt's in-order retirement and cost ~0.3 ms per launch when issued every row.
-        if (t % RB == RB - 1 || y == 0) {
-            const int nrows = t % RB + 1, ytop = y;   // buffered rows: LDS row r holds image row ytop + (nrows - 1 - r)
-            __syncthreads();
-            for (int i = threadIdx.x; i < nrows * COLS; i += 256) {
-                const int r = i / COLS, c = i - r * COLS;
-                if (x0 + c < g.w && !(CART_FUSED_ABLATE & 16))
-                    a.wta_l[(size_t)frame * g.npx + (size_t)(ytop + nrows - 1 - r) * g.w + x0 + c] = s_out[r][c];
-            }
-            for (int i = threadIdx.x; i < nrows * NRP; i += 256) {
-                const int r = i / NRP, c = i - r * NRP;
-                const uint32_t v = s_rmin[r][c];
-                s_rmin[r][c] = 0xffffffffu;
-                if (!(CART_FUSED_ABLATE & 8))
-                    a.partial[(((size_t)frame * g.h + (ytop + nrows - 1 - r)) * nblk + blk) * NRP + c] = v;
-            }
-            __syncthreads();
+        for (int i = threadIdx.x; i < nrows * NRP; i += NT) {
+            const int r = i / NRP, c = i - r * NRP;
+            const uint32_t v = s_rmin[r][c];
+            s_rmin[r][c] = 0xffffffffu;
+            if (!(CART_FUSED_ABLATE & 8))
+                a.partial[(((size_t)frame * g.h + (ytop + nrows - 1 - r)) * nblk + blk) * NRP + c] = v;
         }
+        __syncthreads();
     };
 
     __syncthreads();
-    FusedRegs<LPP, NP> ra, rb;
-    load_row(g.h - 1, ra);
-    for (int t = 0; t < g.h; t += 2) {
-        const int y = g.h - 1 - t;
-        load_row(max(y - 1, 0), rb);
-        step(t, y, ra);
-        load_row(max(y - 2, 0), ra);
-        if (y - 1 >= 0) step(t + 1, y - 1, rb);
+    load_census_row(g.h - 1);
+    load_slab_row(g.h - 1, std::integral_constant<int, 0>{});
+    load_slab_row(max(g.h - 2, 0), std::integral_constant<int, 1>{});
+    // Rows in chunks of RB, two rows per iteration (slab set 0, slab set 1), straight-line.  An odd last row runs after
+    // the loop: inside it the compiler would have to assume "odd row, then another chunk", i.e. set 0 consumed twice in
+    // a row, and would shrink the counted wait of set 0 to vmcnt(4) -- one slab row in flight instead of two.
+    const int h_even = g.h & ~1;
+    for (int t0 = 0; t0 < h_even; t0 += RB) {
+        const int nrows = min(RB, h_even - t0);
+        for (int k = 0; k < nrows; k += 2) {
+            step(t0 + k, k, g.h - 1 - (t0 + k), std::integral_constant<int, 0>{});
+            step(t0 + k + 1, k + 1, g.h - 2 - (t0 + k), std::integral_constant<int, 1>{});
+        }
+        flush(nrows, g.h - (t0 + nrows));
+    }
+    if (g.h & 1) {
+        step(h_even, 0, 0, std::integral_constant<int, 0>{});
+        flush(1, 0);
     }
 }
 
@@ -875,16 +918,16 @@ __global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, 
 }
 
 size_t wta_fused_partial_elems(const Geometry &g) {
-    const int cols = 4 * (64 / (g.D / 16));
+    const int cols = fused_waves(g.D / 16) * (64 / (g.D / 16));
     return (size_t)g.h * ((g.w + cols - 1) / cols) * (cols + g.D);
 }
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s) {
     FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq};
-    const int cols = 4 * (64 / (g.D / 16));
+    const int cols = fused_waves(g.D / 16) * (64 / (g.D / 16));
     const int nblk = (g.w + cols - 1) / cols;
-    dim3 grid(nblk * n_frames), block(256);
+    dim3 grid(nblk * n_frames), block(64 * fused_waves(g.D / 16));
     if (g.P == 4) {
         switch (g.D) {
             case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 4>), grid, block, 0, s, a); break;
