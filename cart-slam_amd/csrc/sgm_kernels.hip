@@ -663,9 +663,9 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 //     (ds_min_u32); the block's NR = 4P + D - 1 minima of the row go to a per-block partial buffer with plain stores
 //     and rv_merge_kernel takes the min over the <= ceil((D-1)/4P)+1 blocks that cover a right pixel (global atomics
 //     straight from this kernel cost 0.16 ms per 16-frame launch, the partial buffer is 2 % of the slab traffic).
-// The LDS tile is double buffered (one barrier per step); left disparities and right-view minima are buffered in LDS
-// for 16 rows and written out in one burst, so the row loop itself holds loads only and the prefetch of row y-1
-// stays in flight while row y is processed.
+// The row loop has no block barrier (the LDS sum tile is only read by the wave that wrote it); left disparities and
+// right-view minima are buffered in LDS for 16 rows and written out in one burst between two barriers, so the row
+// loop itself holds loads only and the prefetches stay in flight while a row is processed.
 #ifndef CART_FUSED_ABLATE
 #define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view
 #endif
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 12 / fused_waves(LPP)) void 
     constexpr int WPB = fused_waves(LPP), NT = 64 * WPB;
     constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
     __shared__ uint32_t s_win[WPB][WN::BUF];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tile[2][COLS * D];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * D];
     constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores
     __shared__ uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
@@ -807,8 +807,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 12 / fused_waves(LPP)) void 
         __builtin_amdgcn_sched_barrier(0);
         load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
         __builtin_amdgcn_sched_barrier(0);
-        const int b = t & 1;
-        uint16_t *tile = &s_tile[b][0];
+        uint16_t *tile = &s_tile[0][0];   // single buffer: every wave only touches the rows of its own pixels
         v4u *dst = reinterpret_cast<v4u *>(tile + xl * D + d0);
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
         dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
@@ -839,7 +838,8 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 12 / fused_waves(LPP)) void 
                 atomicMin(rm - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
             }
         }
-        __syncthreads();
+        // No block barrier here: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave
+        // (LDS operations of one wave execute in order); the block-wide arrays (s_rmin, s_rec) are only read in the burst.
         // ---- the pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
         // deferred to the burst below, where all lanes work on it
         if (gl == 0) {
