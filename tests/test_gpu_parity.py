@@ -403,10 +403,16 @@ def test_reproject_depth_batched(torch_cuda):
     eng.close()
 
 
-def test_randomized_configurations(torch_cuda):
+@pytest.mark.parametrize("fused", [False, True])
+def test_randomized_configurations(torch_cuda, fused, monkeypatch):
     """Seeded sweep over sizes / D / paths / min_disparity / P1 / P2 / uniqueness / smoothing, incl. the extremes
-    (uniqueness 0 and 100, min_disparity 0 and 64, width < D, 1-pixel-ragged tiles); every output bit-exact."""
+    (uniqueness 0 and 100, min_disparity 0 and 64, width < D, 1-pixel-ragged tiles); every output bit-exact -- once
+    through the two-kernel WTA and once with the fused WTA forced for every call."""
     torch = torch_cuda
+    if fused:
+        monkeypatch.setenv("CART_FUSED_MIN_FRAMES", "1")
+    else:
+        monkeypatch.setenv("CART_FUSED_WTA", "0")
     rng = np.random.default_rng(20260101)
     cases = []
     for i in range(28):
