@@ -202,6 +202,21 @@ class Engine:
                                                              up, us, op, os_, _stream_ptr()), "cart_superpixel_plane_classify")
         return uns, out
 
+    # ---- optical flow (stand-in for src/modules/optflow.cpp; oracle S15) ----
+    def optical_flow(self, cur, prev, radius=8, block=2):
+        """cur/prev: uint8 [h,w] or [h,w,3] -> int16 [h,w,2] S10.5 flow (previous position = p - (flow >> 5))."""
+        import torch
+        ch = 3 if cur.dim() == 3 else 1
+        _, cp, cs, _ = _geom(cur, 2 if ch == 3 else 1)
+        _, pp, ps, _ = _geom(prev, 2 if ch == 3 else 1)
+        if tuple(cur.shape[:2]) != (self.height, self.width) or cur.shape != prev.shape:
+            raise EngineError("image shape does not match the engine")
+        out = torch.empty((self.height, self.width, 2), dtype=torch.int16, device=cur.device)
+        _, op, os_, _ = _geom(out, 2)
+        self._check(self._lib.cart_optical_flow(self._h, cp, cs, pp, ps, ch, int(radius), int(block), op, os_, _stream_ptr()),
+                    "cart_optical_flow")
+        return out
+
     # ---- depth module (reference src/modules/depth.cpp:9-25) ----
     def reproject_depth(self, disp, Q):
         import torch

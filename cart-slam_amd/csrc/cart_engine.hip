@@ -66,6 +66,7 @@ struct cart_engine {
     int16_t *tmp_a = nullptr, *tmp_b = nullptr;  // tight s16 planes (interpolate ping-pong)
     int32_t *ccl_work = nullptr;
     uint32_t *rv_partial = nullptr; // [max_inflight][wta_fused_partial_elems], allocated by the first fused batch
+    uint8_t *flow_ws = nullptr;     // [max_inflight][flow_ws_bytes]: gray x2, census x2, scratch; first cart_optical_flow allocates
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
@@ -297,7 +298,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
@@ -876,6 +877,41 @@ int cart_superpixel_plane_classify(cart_engine *e, const int16_t *deriv2, size_t
     release(lease);
     if (err != hipSuccess) return fail(std::string("hipMemsetAsync: ") + hipGetErrorString(err));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- optical flow (oracle S15) ----
+int cart_optical_flow(cart_engine *e, const uint8_t *cur, size_t cur_step, const uint8_t *prev, size_t prev_step, int channels,
+                      int radius, int block, int16_t *flow, size_t flow_step, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!cur || !prev || !flow) return fail("NULL image pointer");
+    if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
+    if (radius < 1 || radius > 16) return fail("radius must be in [1, 16]");
+    if (block < 1 || block > 3) return fail("block must be in [1, 3]");
+    const Geometry &g = e->g;
+    if (cur_step < (size_t)g.w * channels || prev_step < (size_t)g.w * channels) return fail("input step smaller than a row");
+    if (flow_step < (size_t)g.w * 4 || (flow_step & 3) || (reinterpret_cast<uintptr_t>(flow) & 3)) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    const size_t cen_bytes = g.census_elems * sizeof(uint32_t);
+    const size_t ws_bytes = ((2 * g.npx + 255) & ~(size_t)255) + 2 * cen_bytes + g.npx * sizeof(uint32_t);
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->flow_ws) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->flow_ws), e->slots.size() * ws_bytes));
+    }
+    Lease l;
+    if (acquire(e, 1, stream, &l)) return -1;
+    uint8_t *ws = e->flow_ws + (size_t)l.s0 * ws_bytes;
+    uint8_t *gray_c = ws, *gray_p = ws + g.npx;
+    uint32_t *cen_c = reinterpret_cast<uint32_t *>(ws + ((2 * g.npx + 255) & ~(size_t)255));
+    uint32_t *cen_p = cen_c + g.census_elems;
+    uint32_t *scratch = cen_p + g.census_elems;   // census_kernel also resets a right-view plane: unused here
+    ImageBatch cb{cur, cur_step, 0}, pb{prev, prev_step, 0};
+    launch_census(cb, pb, channels, 1, gray_c, gray_p, cen_c, cen_p, scratch, g, stream);
+    launch_block_flow(cen_c, cen_p, g, radius, block, flow, flow_step, stream);
+    hipError_t err = hipGetLastError();
+    release(l);
+    if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
     return 0;
 }
 

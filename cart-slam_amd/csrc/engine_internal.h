@@ -139,6 +139,10 @@ struct SpClassifyArgs {
 };
 void launch_sp_classify(const SpClassifyArgs &a, hipStream_t s);
 
+// ---- optical flow (flow_kernels.hip) ----
+void launch_block_flow(const uint32_t *cen_cur, const uint32_t *cen_prev, const Geometry &g, int radius, int block, int16_t *flow,
+                       size_t flow_step, hipStream_t s);
+
 int kernel_count();
 
 }  // namespace cart_amd

@@ -441,6 +441,6 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 35; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 12 + superpixel_kernels 8
+int kernel_count() { return 38; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 12 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

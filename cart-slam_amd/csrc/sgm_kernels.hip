@@ -695,7 +695,7 @@ struct FusedRegs {
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
 template <int LPP, int NP>
-__global__ __launch_bounds__(64 * fused_waves(LPP), 12 / fused_waves(LPP)) void wta_fused_kernel(FusedArgs a) {  // 3 waves per SIMD
+__global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU)
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = fused_waves(LPP), NT = 64 * WPB;

@@ -222,6 +222,14 @@ int cart_superpixel_plane_classify(cart_engine *engine, const int16_t *deriv2, s
                                    uint8_t *planes_unsmoothed, size_t planes_unsmoothed_step,
                                    uint8_t *planes, size_t planes_step, void *stream);
 
+/* Stand-in for ImageOpticalFlowModule's device work (src/modules/optflow.cpp:96-140: cvtColor x2 +
+ * cv::cuda::NvidiaOpticalFlow_2_0::calc(current, previous), NVIDIA fixed-function hardware): dense census block
+ * matching (oracle S15).  cur / prev = the reference images of frame id and id-1 (1-channel gray or 3-channel BGR),
+ * flow = CV_16SC2 in S10.5 like the reference's (include/modules/optflow.hpp:16); previous position = p - (flow >> 5).
+ * radius = search range in pixels (1..16), block = half window (1..3 -> 3x3, 5x5, 7x7). */
+int cart_optical_flow(cart_engine *engine, const uint8_t *cur, size_t cur_step, const uint8_t *prev, size_t prev_step,
+                      int channels, int radius, int block, int16_t *flow, size_t flow_step, void *stream);
+
 /* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
 

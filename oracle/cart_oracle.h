@@ -63,6 +63,15 @@
  *                 CPU and GPU agree bit for bit).
  *  S14 YCrCb    = OpenCV 8-bit BGR2YCrCb: Y as S1; Cr = ((R-Y)*11682 + (128<<14) + 8192) >> 14;
  *                 Cb = ((B-Y)*9241 + (128<<14) + 8192) >> 14, arithmetic shift, saturated to u8; stored (Y,Cr,Cb).
+ *  S15 optical flow (stand-in provider of "optflow"; the reference's is NVIDIA fixed-function hardware,
+ *                 src/modules/optflow.cpp:57-70, so there is nothing to restate): census block matching, integer pixels.
+ *                 For the current pixel p and a displacement (u,v), |u|,|v| <= R:
+ *                   cost(p,u,v) = sum over q in the (2B+1)x(2B+1) window around p, q inside the image, of
+ *                                 popcount(cenC(q) ^ cenP(q - (u,v))),  cenP = 0 outside the image (like S3);
+ *                 cenC / cenP = S2 features of the current / previous gray image.  The winner starts as (0,0) and is
+ *                 replaced only by a strictly smaller cost, candidates visited v = -R..R outer, u = -R..R inner.
+ *                 flow = (32u, 32v) as S10.5 (include/modules/optflow.hpp:16): the previous position of p is
+ *                 p - (flow >> 5), which is how planeseg.cu:212-219 consumes it.
  */
 #ifndef CART_ORACLE_H
 #define CART_ORACLE_H
@@ -193,6 +202,10 @@ long cart_oracle_sp_relax(const cart_oracle_sp_params *p, uint16_t *labels, int 
 void cart_oracle_sp_classify(const int16_t *deriv2, const uint16_t *labels, int w, int h, int max_label,
                              const cart_oracle_plane_params *params, int n_prev, const uint8_t *const *prev_planes,
                              const int16_t *const *flows, uint8_t *planes_unsmoothed, uint8_t *planes);
+
+/* S15: census planes tight [h][w] u32 of the current and the previous frame -> flow tight [h][w][2] s16 (S10.5). */
+void cart_oracle_block_flow(const uint32_t *cen_cur, const uint32_t *cen_prev, int w, int h, int radius, int block,
+                            int16_t *flow);
 
 #ifdef __cplusplus
 }

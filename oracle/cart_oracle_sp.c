@@ -303,3 +303,32 @@ void cart_oracle_sp_classify(const int16_t *deriv2, const uint16_t *labels, int 
         }
     free(votes);
 }
+
+/* ---- S15 optical flow (census block matching) ------------------------------------------------------------------- */
+void cart_oracle_block_flow(const uint32_t *cen_cur, const uint32_t *cen_prev, int w, int h, int radius, int block,
+                            int16_t *flow) {
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            long best = -1;
+            int bu = 0, bv = 0;
+            for (int pass = 0; pass < 2; ++pass) {            /* pass 0: (0,0); pass 1: the scan */
+                for (int v = pass ? -radius : 0; v <= (pass ? radius : 0); ++v)
+                    for (int u = pass ? -radius : 0; u <= (pass ? radius : 0); ++u) {
+                        if (pass && u == 0 && v == 0) continue;
+                        long c = 0;
+                        for (int dy = -block; dy <= block; ++dy)
+                            for (int dx = -block; dx <= block; ++dx) {
+                                const int qx = x + dx, qy = y + dy;
+                                if (qx < 0 || qy < 0 || qx >= w || qy >= h) continue;
+                                const int px = qx - u, py = qy - v;
+                                const uint32_t fp = (px < 0 || py < 0 || px >= w || py >= h) ? 0u : cen_prev[(size_t)py * w + px];
+                                c += __builtin_popcount(cen_cur[(size_t)qy * w + qx] ^ fp);
+                            }
+                        if (best < 0 || c < best) { best = c; bu = u; bv = v; }
+                    }
+            }
+            flow[((size_t)y * w + x) * 2] = (int16_t)(bu * 32);
+            flow[((size_t)y * w + x) * 2 + 1] = (int16_t)(bv * 32);
+        }
+}

@@ -410,3 +410,32 @@ def sp_classify(deriv2, labels, max_label, params, prev_planes=(), flows=()):
     mx[sel] = votes[sel, 1]
     assign[votes[:, 0] > mx] = 0
     return uns, assign[labels.astype(np.int64)]
+
+
+# ---- S15 optical flow: array-shift formulation with a summed-area table ----------------------------------------------
+def block_flow(cen_cur, cen_prev, radius, block):
+    h, w = cen_cur.shape
+    R, B = radius, block
+    padp = np.zeros((h + 2 * R, w + 2 * R), np.uint32)
+    padp[R:R + h, R:R + w] = cen_prev
+
+    def cost(u, v):
+        shifted = padp[R - v:R - v + h, R - u:R - u + w]          # cenP(q - (u, v)), zero outside the image
+        x = cen_cur ^ shifted
+        ham = np.zeros((h, w), np.int64)
+        for k in range(32):
+            ham += (x >> np.uint32(k)) & np.uint32(1)
+        sat = np.zeros((h + 1, w + 1), np.int64)
+        sat[1:, 1:] = ham.cumsum(0).cumsum(1)
+        y0 = np.clip(np.arange(h) - B, 0, h); y1 = np.clip(np.arange(h) + B + 1, 0, h)
+        x0 = np.clip(np.arange(w) - B, 0, w); x1 = np.clip(np.arange(w) + B + 1, 0, w)
+        return sat[y1][:, x1] - sat[y0][:, x1] - sat[y1][:, x0] + sat[y0][:, x0]
+
+    best = cost(0, 0)
+    bu = np.zeros((h, w), np.int64); bv = np.zeros((h, w), np.int64)
+    for v in range(-R, R + 1):
+        for u in range(-R, R + 1):
+            c = cost(u, v)
+            upd = c < best
+            best = np.where(upd, c, best); bu = np.where(upd, u, bu); bv = np.where(upd, v, bv)
+    return np.stack([bu * 32, bv * 32], axis=-1).astype(np.int16)

@@ -273,3 +273,12 @@ def sp_classify(deriv2, labels, max_label, params, prev_planes=(), flows=()):
     out = np.empty((h, w), np.uint8)
     lib().cart_oracle_sp_classify(_p(d2), _p(lb), w, h, int(max_label), C.byref(pp), n, pa, fa, _p(uns), _p(out))
     return uns, out
+
+
+def block_flow(gray_cur, gray_prev, radius=8, block=2):
+    """S15: -> int16 [h,w,2] S10.5 flow (previous position = p - (flow >> 5))."""
+    h, w = gray_cur.shape
+    cc = np.ascontiguousarray(census(gray_cur)); cp = np.ascontiguousarray(census(gray_prev))
+    out = np.empty((h, w, 2), np.int16)
+    lib().cart_oracle_block_flow(_p(cc), _p(cp), w, h, int(radius), int(block), _p(out))
+    return out

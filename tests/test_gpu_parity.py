@@ -614,3 +614,35 @@ def test_tile_loaders_on_the_reference_ramp(torch_cuda):
     want, changes = O.sp_relax(O.sp_params(), lab, mx, O.bgr2ycrcb(bgr), edd, 2)
     assert changes > 0 and (got == want).all()
     sp.close(); geo.close()
+
+
+def test_optical_flow_block_matching(torch_cuda):
+    """cart_optical_flow (stand-in for the reference's NVIDIA hardware flow, oracle S15): census block matching, every
+    flow vector bit-exact, incl. borders, BGR input, ragged sizes and frames without texture."""
+    torch = torch_cuda
+    for (w, h, R, B, ch) in ((200, 80, 6, 2, 1), (131, 53, 4, 1, 3), (64, 16, 8, 3, 1), (333, 41, 16, 2, 1)):
+        eng = make_engine(w, h, 0, 0)
+        cur, _, _ = synth.make_pair(w, h, 64, 4, seed=50 + w, frame=1, channels=ch)
+        prev, _, _ = synth.make_pair(w, h, 64, 4, seed=50 + w, frame=0, channels=ch)   # scene translated by 2 px per frame
+        got = eng.optical_flow(dev(torch, cur), dev(torch, prev), R, B).cpu().numpy()
+        gc = cur if ch == 1 else O.bgr2gray(cur)
+        gp = prev if ch == 1 else O.bgr2gray(prev)
+        exp = O.block_flow(gc, gp, R, B)
+        assert (got == exp).all(), (w, h, R, B, ch, int((got != exp).any(axis=-1).sum()))
+        assert (exp != 0).any()
+        flat = np.full(cur.shape, 77, np.uint8)
+        assert (eng.optical_flow(dev(torch, flat), dev(torch, flat), R, B).cpu().numpy() == 0).all()
+        eng.close()
+    # full KITTI size against the oracle + recovery of a known global shift in the interior
+    w, h, R, B = 1242, 375, 8, 2
+    eng = make_engine(w, h, 0, 0)
+    cur, _, _ = synth.make_pair(w, h, 128, 4, seed=9)
+    prev = np.roll(cur, (-3, 5), axis=(0, 1))          # prev(p - (u,v)) = cur(p) with (u,v) = (-5, 3)
+    got = eng.optical_flow(dev(torch, cur), dev(torch, prev), R, B).cpu().numpy()
+    exp = O.block_flow(cur, prev, R, B)
+    assert (got == exp).all()
+    inner = got[20:-20, 20:-20]
+    assert ((inner[..., 0] == -5 * 32) & (inner[..., 1] == 3 * 32)).mean() > 0.999
+    with pytest.raises(Exception):
+        eng.optical_flow(dev(torch, cur), dev(torch, prev), 17, 2)
+    eng.close()

@@ -288,3 +288,22 @@ def test_golden_superpixel_fixtures():
             assert (labels == z[f"labels{k}"]).all(), (f, k)
             uns, pl = O.sp_classify(z[f"deriv{k}"], labels, mx, tuple(int(v) for v in z["plane_params"]))
             assert (uns == z[f"unsmoothed{k}"]).all() and (pl == z[f"planes{k}"]).all(), (f, k)
+
+
+# ---- optical flow (S15) ---------------------------------------------------------------------------------------------
+def test_block_flow_matches_numpy_and_recovers_shifts():
+    rng = np.random.default_rng(6)
+    w, h = 70, 44
+    cur = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    prev = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    prev[5:30, 8:50] = cur[7:32, 5:47]       # a patch that moved by (u, v) = (-3, +2): prev(p - (u,v)) = cur(p)
+    for R, B in ((3, 1), (4, 2)):
+        a = O.block_flow(cur, prev, R, B)
+        b = N.block_flow(O.census(cur), O.census(prev), R, B)
+        assert (a == b).all(), (R, B)
+    inner = a[14:24, 16:40]
+    assert (inner[..., 0] == -3 * 32).all() and (inner[..., 1] == 2 * 32).all()
+    # identical frames -> zero flow everywhere (ties keep (0,0)); a flat image too
+    assert (O.block_flow(cur, cur, 3, 2) == 0).all()
+    flat = np.full((h, w), 90, np.uint8)
+    assert (O.block_flow(flat, flat, 3, 2) == 0).all()
