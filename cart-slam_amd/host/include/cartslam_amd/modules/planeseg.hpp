@@ -119,6 +119,20 @@ class SuperPixelDisparityPlaneSegmentationModule : public SyncWrapperSystemModul
 
 typedef int16_t optical_flow_t;  // S10.5, two channels (include/modules/optflow.hpp)
 
+// mirrors include/modules/optflow.hpp:23-41 + src/modules/optflow.cpp:52-140: same name, key and frame logic (no flow for
+// the first frame; flow between the reference images of frame id and id-1).  The reference computes it on NVIDIA's
+// fixed-function optical-flow engine (cv::cuda::NvidiaOpticalFlow_2_0, grid size 1, S10.5); here it is dense census block
+// matching (cart_optical_flow, oracle S15) with the same output format.  searchRadius / blockRadius are extensions.
+class ImageOpticalFlowModule : public SyncWrapperSystemModule {
+   public:
+    explicit ImageOpticalFlowModule(const Size imageRes, int searchRadius = 8, int blockRadius = 2);
+    system_data_t runInternal(System &system, SystemRunData &data) override;
+
+   private:
+    std::shared_ptr<EngineHandle> engine;
+    const int searchRadius, blockRadius;
+};
+
 // Stand-in provider of "optflow": <sequence dir>/flow/%06d.bin, raw int16 [h][w][2], frame index = run id - 1.
 class OpticalFlowFileModule : public SyncWrapperSystemModule {
    public:

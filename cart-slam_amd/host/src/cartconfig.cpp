@@ -103,9 +103,8 @@ void applyModuleConfig(const Value &modulesConfig, std::shared_ptr<System> syste
                                                                           (unsigned)get(moduleConfig, "temporal_smoothing_distance", CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT));
         } else if (moduleType == "optflow_file") {  // extension: replays flow fields from <sequence>/flow/%06d.bin
             system->addModule<OpticalFlowFileModule>();
-        } else if (moduleType == "optflow") {
-            throw std::runtime_error("Module type optflow needs cv::cuda::NvidiaOpticalFlow_2_0 (NVIDIA fixed-function hardware): not supported; "
-                                     "any module providing \"optflow\" (e.g. optflow_file) feeds temporal smoothing.");
+        } else if (moduleType == "optflow") {  // cartconfig.cpp:183-185; search_radius / block_radius are extensions
+            system->addModule<ImageOpticalFlowModule>(dataSource->getImageSize(), get(moduleConfig, "search_radius", 8), get(moduleConfig, "block_radius", 2));
         } else if (endsWith(moduleType, "_visualization")) {
             std::cerr << "[cartconfig] skipping GUI module type " << moduleType << " (out of scope)\n";
         } else {

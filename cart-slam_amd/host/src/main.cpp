@@ -45,7 +45,7 @@ int main(int argc, char **argv) {
         }
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
-                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS};
+                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS, CARTSLAM_KEY_OPTFLOW};
             for (int id = 1; id <= frames; ++id) {
                 std::shared_ptr<cart::SystemRunData> run;
                 try { run = system->getRunById((uint32_t)id); } catch (const std::exception &) { continue; }  // evicted (retention ring)
@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
                 for (const char *k : keys) {
                     if (!run->hasData(k)) continue;
                     auto img = run->getData<cart::image_t>(k);
+                    if (!img) continue;  // e.g. "optflow" of the first frame (optflow.cpp:126-128)
                     auto bytes = img->downloadTight();
                     std::ofstream o(dump + "/" + std::to_string(id) + "_" + k + ".bin", std::ios::binary);
                     o.write(reinterpret_cast<const char *>(bytes.data()), (std::streamsize)bytes.size());

@@ -395,6 +395,31 @@ void SuperPixelDisparityPlaneSegmentationModule::updatePlaneParameters(System &s
     system.insertGlobalData(CARTSLAM_KEY_DISPARITY_DERIVATIVE_HIST, std::make_shared<std::vector<int32_t>>(histogram));
 }
 
+// ---------------------------------------------------------------- optical flow (optflow.cpp:52-140)
+ImageOpticalFlowModule::ImageOpticalFlowModule(const Size imageRes, int searchRadius, int blockRadius)
+    : SyncWrapperSystemModule("ImageOpticalFlow"), searchRadius(searchRadius), blockRadius(blockRadius) {
+    if (searchRadius < 1 || searchRadius > 16) throw std::invalid_argument("search_radius must be in [1, 16]");
+    if (blockRadius < 1 || blockRadius > 3) throw std::invalid_argument("block_radius must be in [1, 3]");
+    this->providesData.push_back(CARTSLAM_KEY_OPTFLOW);
+    engine = std::make_shared<EngineHandle>(imageRes, paramsFor(imageRes, 0, 0, -1, 0, 0, 10, 120, 12));
+}
+
+system_data_t ImageOpticalFlowModule::runInternal(System &, SystemRunData &data) {
+    if (data.id <= 1) return MODULE_RETURN(CARTSLAM_KEY_OPTFLOW, std::shared_ptr<void>());  // first run, no previous data (optflow.cpp:126-128)
+    std::shared_ptr<SystemRunData> previousRun = data.getRelativeRun(-1);
+    const image_t referenceCurrent = getReferenceImage(data.dataElement);
+    const image_t referencePrevious = getReferenceImage(previousRun->dataElement);
+    if ((referenceCurrent.type() != CV_8UC1 && referenceCurrent.type() != CV_8UC3) || referencePrevious.type() != referenceCurrent.type())
+        throw std::runtime_error("ImageOpticalFlowModule requires CV_8UC1 or CV_8UC3 images");
+    auto flow = std::make_shared<image_t>(referenceCurrent.rows, referenceCurrent.cols, CV_16SC2);
+    ScopedStream stream;
+    if (cart_optical_flow(engine->get(), referenceCurrent.ptr<uint8_t>(), referenceCurrent.step, referencePrevious.ptr<uint8_t>(), referencePrevious.step,
+                          referenceCurrent.type() == CV_8UC3 ? 3 : 1, searchRadius, blockRadius, flow->ptr<int16_t>(), flow->step, stream.s) != 0)
+        engine->fail("cart_optical_flow");
+    stream.wait();
+    return MODULE_RETURN(CARTSLAM_KEY_OPTFLOW, flow);
+}
+
 system_data_t OpticalFlowFileModule::runInternal(System &system, SystemRunData &data) {
     const std::string dir = system.getDataSource()->getPath();
     const Size size = system.getDataSource()->getImageSize();

@@ -249,13 +249,13 @@ def test_temporal_smoothing_frame_loop(tmp_path):
             fl = [flows[f - i] for i in range(0, k)]               # flow of frames id, id-1, ...
             exp = O.temporal_vote(cur, prev, fl)
         assert (load(tmp, fid, "planes", np.uint8, (h, w)) == exp).all(), f"smoothed frame {fid}"
-    # the reference's own provider of "optflow" is NVIDIA hardware: asking for it must fail loudly
-    r = run_exe(src, [{"type": "optflow"}], tmp)
-    assert r.returncode != 0 and "not supported" in r.stderr
+    # bad parameters of the native "optflow" stand-in fail loudly
+    r = run_exe(src, [{"type": "optflow", "search_radius": 40}], tmp)
+    assert r.returncode != 0 and "search_radius must be in [1, 16]" in r.stderr
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("temporal", [False, True])
+@pytest.mark.parametrize("temporal", [False, "file", "native"])
 def test_superpixel_planeseg_frame_loop(tmp_path, temporal):
     """The reference's plane-segmentation configuration (config/modules/kitti-planeseg.json: superpixels, disparity,
     disparity_derivative, superpixel_disparity_planeseg with the histogram_peak provider; "optflow" replaced by the file
@@ -264,7 +264,9 @@ def test_superpixel_planeseg_frame_loop(tmp_path, temporal):
     w, h, n, bs, reset = 320, 96, 7, 8, 4
     src, frames = make_dataset(tmp, n, w, h, channels=3)
     flows = []
-    if temporal:
+    if temporal == "native":  # the "optflow" module type itself (census block matching, oracle S15)
+        flows = [None] + [O.block_flow(O.bgr2gray(frames[f][0]), O.bgr2gray(frames[f - 1][0]), 4, 2) for f in range(1, n)]
+    elif temporal:
         fdir = os.path.join(tmp, "dataset", "sequences", "00", "flow")
         os.makedirs(fdir)
         rng = np.random.default_rng(18)
@@ -276,10 +278,10 @@ def test_superpixel_planeseg_frame_loop(tmp_path, temporal):
                {"type": "disparity", "num_disparities": 64, "smoothing_radius": 2, "smoothing_iterations": 1},
                {"type": "disparity_derivative"},
                {"type": "superpixel_disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}, "update_interval": 2, "reset_interval": 2,
-                "use_temporal_smoothing": temporal},
+                "use_temporal_smoothing": bool(temporal)},
                {"type": "disparity_planeseg_visualization", "show_histogram": False}]
     if temporal:
-        modules.insert(1, {"type": "optflow_file"})
+        modules.insert(1, {"type": "optflow", "search_radius": 4} if temporal == "native" else {"type": "optflow_file"})
     r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump")))
     assert r.returncode == 0, r.stderr
     sp = O.sp_params()  # JSON factory defaults (cartconfig.cpp:128-133)
@@ -312,6 +314,8 @@ def test_superpixel_planeseg_frame_loop(tmp_path, temporal):
             k = min(3, fid - 1)
             prev = [unsm[f - i] for i in range(1, k + 1)]
             fl = [flows[f - i] for i in range(0, k)]
+        if temporal == "native" and fid > 1:
+            assert (load(tmp, fid, "optflow", np.int16, (h, w, 2)) == flows[f]).all(), f"optflow frame {fid}"
         eu, ep = O.sp_classify(d2, labels, mx, params, prev, fl)
         unsm.append(eu)
         assert (load(tmp, fid, "planes_unsmoothed", np.uint8, (h, w)) == eu).all(), f"unsmoothed frame {fid}"
