@@ -1,7 +1,8 @@
 // modules/planeseg.hpp -- mirrors include/modules/planeseg.hpp:15-162 (keys, Plane, PlaneParameters, the two
 // parameter providers, DisparityPlaneSegmentationModule incl. temporal smoothing).  Temporal smoothing consumes the
 // "optflow" key (S10.5 CV_16SC2); the reference's provider of that key is NVIDIA fixed-function hardware
-// (src/modules/optflow.cpp) and out of scope, so any module providing "optflow" will do (OpticalFlowFileModule below
+// (src/modules/optflow.cpp): ImageOpticalFlowModule below provides it by census block matching, and any other module
+// providing "optflow" will do (OpticalFlowFileModule
 // replays flow fields from files).
 #pragma once
 #include <mutex>

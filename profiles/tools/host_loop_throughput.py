@@ -22,7 +22,8 @@ for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "nu
                                                         {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
                    ("reference default (D=256, 4 paths) + planeseg", [{"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1},
                                                                       {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
-                   ("kitti-planeseg.json (superpixels 24/8 sweeps, D=256 4 paths, derivative, depth, superpixel planeseg)", SP)):
+                   ("kitti-planeseg.json minus optflow (superpixels 24/8 sweeps, D=256 4 paths, derivative, depth, superpixel planeseg)", SP),
+                   ("kitti-planeseg.json complete (+ optflow stand-in R=8, temporal smoothing)", SP[:1] + [{"type": "optflow"}] + SP[1:-1] + [dict(SP[-1], use_temporal_smoothing=True)])):
     json.dump(mods, open(tmp + "/mod.json", "w"))
     exe = os.path.join(ROOT, "cart-slam_amd", "build", "cart_slam_amd")
     t0 = time.time()
@@ -40,7 +41,7 @@ for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "nu
     fr.sort(key=lambda x: int(x[1]))
     inits = [int(x[2]) for x in fr]
     print("   frame init spacing ms:", [b - a for a, b in zip(inits[:16], inits[1:17])], " frame durations us:", [int(x[6]) for x in fr[:12]])
-    for mod in ("PlaneSegmentation", "SuperPixelDetect", "SPPlaneSegmentation", "ImageDisparityDerivative", "Depth"):
+    for mod in ("PlaneSegmentation", "SuperPixelDetect", "SPPlaneSegmentation", "ImageDisparityDerivative", "Depth", "ImageOpticalFlow"):
         ps = [int(x[6]) for x in rows if x[0] == mod]
         if ps:
             print(f"   median {mod} us:", sorted(ps)[len(ps) // 2])
