@@ -667,13 +667,18 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 // right-view minima are buffered in LDS for 16 rows and written out in one burst between two barriers, so the row
 // loop itself holds loads only and the prefetches stay in flight while a row is processed.
 #ifndef CART_FUSED_ABLATE
-#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view
+#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view, 128 no recurrence, 256 no WTA
 #endif
 // Waves per block of the fused sweep.  The sweep has frames*W/(64/LPP) waves in total (2484 at 16 x 1242, D=128: 2.4 per
 // SIMD), so small blocks spread them evenly over the CUs: with 4-wave blocks a quarter of the CUs carried 3 blocks, the
 // rest 2, and the launch took the time of 3.  D=256 keeps 4 waves: its blocks would otherwise be 8 columns wide and the
 // right-view partial rows (columns + D - 1 entries per block and row) would grow to 17 % of the slab traffic.
 constexpr int fused_waves(int lpp) { return lpp >= 16 ? 4 : 2; }
+
+// Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0): at the
+// end of a burst every wave would sit out the acknowledgement of its global stores (~10 us under this read load), 23
+// times per sweep (0.3 ms per 16-frame launch).  The bursts only exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct FusedArgs {
     const uint32_t *cen_l, *cen_r;
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
     __shared__ uint32_t s_win[WPB][WN::BUF];
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * D];
-    constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores
+    constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores (32 rows cost an LDS-limited block per CU)
     __shared__ uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
     __shared__ uint16_t s_thr[2048];             // uniqueness threshold by best cost (sums are <= 8 * 255)
@@ -775,9 +780,12 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     for (int i = 0; i < 8; ++i) st[i] = 0;
     uint32_t mm = 0;
 
-    auto step = [&](int t, int lr, int y, auto set_c) {   // t: step (tile parity), lr: LDS output row, y: image row
-        constexpr int SET = decltype(set_c)::value;
-        // ---- "up" path costs of row y (oracle S3/S4), registers only
+    // The two halves of a row are split so that they can be software-pipelined: agg(y) advances the "up" path state to
+    // row y (the only cross-row dependency), wta(...) runs the WTA of the PREVIOUS row on a copy of its state.  The two
+    // instruction streams are independent, so the scheduler interleaves them and the long latency chains of one (LDS
+    // round trips, DPP reductions) are filled with the other's work.
+    auto agg = [&](int y) {   // census registers hold row y; they are re-loaded for row y-1 once consumed
+        if (CART_FUSED_ABLATE & 1024) return;   // timing experiment: no census loads, no window staging, no recurrence
 #pragma unroll
         for (int i = 0; i < WN::NLD; ++i) wbuf[64 * i + lane] = r.win[i];
         CensusRegs c;
@@ -785,16 +793,23 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
         win_read<LPP>(wbuf, base_slot, xslot, c.r);
         uint32_t xr[16];
         agg_xor(c, xr);
-        __builtin_amdgcn_sched_barrier(0);
-        load_census_row(max(y - 1, 0));        // the census registers are free again: prefetch the next row
-        __builtin_amdgcn_sched_barrier(0);
-        agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
+        load_census_row(max(y - 1, 0));
+        if (CART_FUSED_ABLATE & 128) {   // timing experiment: no recurrence (keeps the loads and the xor alive)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st[i] ^= xr[i] ^ xr[8 + i];
+        } else {
+            agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
+        }
+    };
+
+    auto wta = [&](const uint32_t (&sp)[8], int lr, int y, auto set_c) {   // sp: path costs of row y; lr: LDS output row
+        constexpr int SET = decltype(set_c)::value;
         // ---- S in natural adjacent pairs: sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q])
         uint32_t sm[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            sm[q] = perm(st[2 * q + 1], st[2 * q], 0x05040100u);
-            sm[4 + q] = perm(st[2 * q + 1], st[2 * q], 0x07060302u);
+            sm[q] = perm(sp[2 * q + 1], sp[2 * q], 0x05040100u);
+            sm[4 + q] = perm(sp[2 * q + 1], sp[2 * q], 0x07060302u);
         }
 #pragma unroll
         for (int k = 0; k < NP - 1; ++k) {
@@ -804,9 +819,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
                 sm[4 + q] += perm(0u, r.sv[SET][k][q], 0x0c030c01u);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
         load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
-        __builtin_amdgcn_sched_barrier(0);
         uint16_t *tile = &s_tile[0][0];   // single buffer: every wave only touches the rows of its own pixels
         v4u *dst = reinterpret_cast<v4u *>(tile + xl * D + d0);
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
@@ -838,10 +851,10 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
                 atomicMin(rm - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
             }
         }
-        // No block barrier here: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave
-        // (LDS operations of one wave execute in order); the block-wide arrays (s_rmin, s_rec) are only read in the burst.
-        // ---- the pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
-        // deferred to the burst below, where all lanes work on it
+        // No block barrier: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave (LDS
+        // operations of one wave execute in order); the block-wide arrays (s_rmin, s_rec) are only read in the burst.
+        // The pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
+        // deferred to the burst, where all lanes work on it.
         if (gl == 0) {
             const int bd = (int)(pk & 0xffffu), bc = (int)(pk >> 16);
             const uint16_t *srow = tile + xl * D;
@@ -853,10 +866,27 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
         }
     };
 
+    // one pipelined iteration: WTA of sweep step r (image row h-1-r) + path costs of step r+1
+    auto iter = [&](int r_, int lr, auto set_c) {
+        uint32_t sp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sp[i] = st[i];
+        agg(g.h - 2 - r_);
+        if (CART_FUSED_ABLATE & 256) {   // timing experiment: no WTA (keeps the slab loads alive through the state)
+            constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+            for (int k = 0; k < NP - 1; ++k) st[k & 7] ^= (r.sv[SET][k][0] ^ r.sv[SET][k][1] ^ r.sv[SET][k][2] ^ r.sv[SET][k][3]) & 1u;
+            load_slab_row(max(g.h - 3 - r_, 0), set_c);
+        } else {
+            wta(sp, lr, g.h - 1 - r_, set_c);
+        }
+    };
+
     // Burst of the buffered rows (LDS row r holds image row ytop + nrows-1-r).  Stores inside the row loop would sit
     // between the prefetch loads in vmcnt's in-order retirement; the row loop itself is branch-free and holds loads only.
     auto flush = [&](int nrows, int ytop) {
-        __syncthreads();
+        if (CART_FUSED_ABLATE & 512) return;   // timing experiment: no burst
+        lds_barrier();
         for (int i = threadIdx.x; i < nrows * COLS; i += NT) {
             const int r = i / COLS, c = i - r * COLS;
             const uint2 rec = s_rec[r][c];
@@ -880,27 +910,33 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
             if (!(CART_FUSED_ABLATE & 8))
                 a.partial[(((size_t)frame * g.h + (ytop + nrows - 1 - r)) * nblk + blk) * NRP + c] = v;
         }
-        __syncthreads();
+        lds_barrier();
     };
 
     __syncthreads();
     load_census_row(g.h - 1);
     load_slab_row(g.h - 1, std::integral_constant<int, 0>{});
     load_slab_row(max(g.h - 2, 0), std::integral_constant<int, 1>{});
-    // Rows in chunks of RB, two rows per iteration (slab set 0, slab set 1), straight-line.  An odd last row runs after
-    // the loop: inside it the compiler would have to assume "odd row, then another chunk", i.e. set 0 consumed twice in
-    // a row, and would shrink the counted wait of set 0 to vmcnt(4) -- one slab row in flight instead of two.
-    const int h_even = g.h & ~1;
-    for (int t0 = 0; t0 < h_even; t0 += RB) {
-        const int nrows = min(RB, h_even - t0);
+    agg(g.h - 1);
+    // Sweep steps r = 0..h-1 (image row h-1-r, slab set r & 1).  The pipelined iterations cover r = 0..h-2 in chunks of RB,
+    // two per loop trip, straight-line; what is left (one pipelined iteration if h-1 is odd, then the WTA of the last row)
+    // runs after the loop: inside it the compiler would have to assume "odd tail, then another chunk" and would shrink the
+    // counted waits of slab set 0 to one row in flight.
+    const int r_even = (g.h - 1) & ~1;
+    for (int r0 = 0; r0 < r_even; r0 += RB) {
+        const int nrows = min(RB, r_even - r0);
         for (int k = 0; k < nrows; k += 2) {
-            step(t0 + k, k, g.h - 1 - (t0 + k), std::integral_constant<int, 0>{});
-            step(t0 + k + 1, k + 1, g.h - 2 - (t0 + k), std::integral_constant<int, 1>{});
+            iter(r0 + k, k, std::integral_constant<int, 0>{});
+            iter(r0 + k + 1, k + 1, std::integral_constant<int, 1>{});
         }
-        flush(nrows, g.h - (t0 + nrows));
+        flush(nrows, g.h - (r0 + nrows));
     }
-    if (g.h & 1) {
-        step(h_even, 0, 0, std::integral_constant<int, 0>{});
+    if ((g.h - 1) & 1) {
+        iter(r_even, 0, std::integral_constant<int, 0>{});
+        wta(st, 1, 0, std::integral_constant<int, 1>{});
+        flush(2, 0);
+    } else {
+        wta(st, 0, 0, std::integral_constant<int, 0>{});
         flush(1, 0);
     }
 }
