@@ -707,13 +707,14 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
     __shared__ uint32_t s_win[WPB][WN::BUF];
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * D];
-    constexpr int RB = 16;                       // rows buffered in LDS between two bursts of global stores (32 rows cost an LDS-limited block per CU)
+    constexpr int RB = 16;                       // rows buffered in LDS between two bursts (= kFusedRB; 32 rows cost an LDS-limited block per CU)
     __shared__ uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
     __shared__ uint16_t s_thr[2048];             // uniqueness threshold by best cost (sums are <= 8 * 255)
     const Geometry &g = a.g;
     const int nblk = (g.w + COLS - 1) / COLS;
     const int frame = blockIdx.x / nblk, blk = blockIdx.x - frame * nblk, x0 = blk * COLS;
+    const int hpad = (g.h + RB - 1) / RB * RB + RB;   // rows of one block in the partial buffer (see flush)
     const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP, d0 = gl * 16;
     const int xl = wid * P + pg, x = x0 + xl;       // column inside the block / the image
@@ -884,10 +885,19 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
 
     // Burst of the buffered rows (LDS row r holds image row ytop + nrows-1-r).  Stores inside the row loop would sit
     // between the prefetch loads in vmcnt's in-order retirement; the row loop itself is branch-free and holds loads only.
-    auto flush = [&](int nrows, int ytop) {
+    // Burst of the buffered rows.  It is branch-free with a fixed number of stores per lane: the partial buffer is laid out
+    // [frame][block][sweep step][NRP] (rows padded to a multiple of RB), so a burst is one linear copy of RB*NRP dwords
+    // (rows past the last one land in the padding), and the few left-disparity stores of dead lanes go to a sink entry.
+    // With a data-dependent store count (or addresses that spill) the compiler cannot count the VMEM operations between
+    // the prefetches issued before the burst and their use after it and waits for everything, including the
+    // acknowledgement of the burst's own stores: ~13 us per burst, 0.3 ms per 16-frame launch.
+    auto flush = [&](int t0, int nrows) {   // LDS row r = sweep step t0 + r = image row h-1-t0-r
         if (CART_FUSED_ABLATE & 512) return;   // timing experiment: no burst
         lds_barrier();
-        for (int i = threadIdx.x; i < nrows * COLS; i += NT) {
+        uint32_t *pbase = a.partial + (((size_t)frame * nblk + blk) * (size_t)hpad + t0) * NRP;
+#pragma unroll
+        for (int i0 = 0; i0 < RB * COLS; i0 += NT) {
+            const int i = min(i0 + (int)threadIdx.x, RB * COLS - 1);
             const int r = i / COLS, c = i - r * COLS;
             const uint2 rec = s_rec[r][c];
             const int bd = (int)(rec.x & 0xffu), bc = (int)(rec.x >> 9), l = (int)(rec.y & 0xffffu), rr = (int)(rec.y >> 16);
@@ -900,15 +910,17 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
                 }
                 out = (uint32_t)subp & 0xffffu;
             }
-            if (x0 + c < g.w && !(CART_FUSED_ABLATE & 16))
-                a.wta_l[(size_t)frame * g.npx + (size_t)(ytop + nrows - 1 - r) * g.w + x0 + c] = (uint16_t)out;
+            const bool live = r < nrows && x0 + c < g.w && i0 + (int)threadIdx.x < RB * COLS;
+            uint16_t *dst = live ? a.wta_l + (size_t)frame * g.npx + (size_t)(g.h - 1 - t0 - r) * g.w + x0 + c
+                                 : reinterpret_cast<uint16_t *>(pbase + NR);   // the pad entry of the chunk's first row
+            *dst = (uint16_t)out;
         }
-        for (int i = threadIdx.x; i < nrows * NRP; i += NT) {
-            const int r = i / NRP, c = i - r * NRP;
-            const uint32_t v = s_rmin[r][c];
-            s_rmin[r][c] = 0xffffffffu;
-            if (!(CART_FUSED_ABLATE & 8))
-                a.partial[(((size_t)frame * g.h + (ytop + nrows - 1 - r)) * nblk + blk) * NRP + c] = v;
+#pragma unroll
+        for (int i0 = 0; i0 < RB * NRP; i0 += NT) {
+            const int i = min(i0 + (int)threadIdx.x, RB * NRP - 1);
+            const uint32_t v = (&s_rmin[0][0])[i];
+            (&s_rmin[0][0])[i] = 0xffffffffu;
+            pbase[i] = v;
         }
         lds_barrier();
     };
@@ -918,6 +930,8 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     load_slab_row(g.h - 1, std::integral_constant<int, 0>{});
     load_slab_row(max(g.h - 2, 0), std::integral_constant<int, 1>{});
     agg(g.h - 1);
+    flush(0, 0);   // writes nothing that survives (chunk 0 is rewritten by its own burst); it only gives the first entry into
+                   // the chunk loop the same VMEM history as every later one, so that the counted waits after a burst stand
     // Sweep steps r = 0..h-1 (image row h-1-r, slab set r & 1).  The pipelined iterations cover r = 0..h-2 in chunks of RB,
     // two per loop trip, straight-line; what is left (one pipelined iteration if h-1 is odd, then the WTA of the last row)
     // runs after the loop: inside it the compiler would have to assume "odd tail, then another chunk" and would shrink the
@@ -925,37 +939,44 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     const int r_even = (g.h - 1) & ~1;
     for (int r0 = 0; r0 < r_even; r0 += RB) {
         const int nrows = min(RB, r_even - r0);
-        for (int k = 0; k < nrows; k += 2) {
+        // the first pair is peeled so that the waits right after a burst are computed for that history alone (20 stores
+        // behind the prefetches) instead of being merged with the loop's back edge
+        iter(r0, 0, std::integral_constant<int, 0>{});
+        iter(r0 + 1, 1, std::integral_constant<int, 1>{});
+        for (int k = 2; k < nrows; k += 2) {
             iter(r0 + k, k, std::integral_constant<int, 0>{});
             iter(r0 + k + 1, k + 1, std::integral_constant<int, 1>{});
         }
-        flush(nrows, g.h - (r0 + nrows));
+        flush(r0, nrows);
     }
     if ((g.h - 1) & 1) {
         iter(r_even, 0, std::integral_constant<int, 0>{});
         wta(st, 1, 0, std::integral_constant<int, 1>{});
-        flush(2, 0);
+        flush(r_even, 2);
     } else {
         wta(st, 0, 0, std::integral_constant<int, 0>{});
-        flush(1, 0);
+        flush(r_even, 1);
     }
 }
 
-// right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p
+// right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p.
+// partial = [frame][block][sweep step t = h-1-y][cols + D] (rows padded, see wta_fused_kernel's flush)
+constexpr int kFusedRB = 16;
 __global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk) {
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
     if (p >= w || y >= h) return;
-    const int nrp = cols + D;
+    const int nrp = cols + D, hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
     const int b0 = p / cols, b1 = min((p + D - 1) / cols, nblk - 1);
-    const uint32_t *row = partial + ((size_t)frame * h + y) * nblk * nrp;
     uint32_t best = 0xffffffffu;
-    for (int b = b0; b <= b1; ++b) best = min(best, row[(size_t)b * nrp + (p - (b * cols - (D - 1)))]);
+    for (int b = b0; b <= b1; ++b)
+        best = min(best, partial[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (p - (b * cols - (D - 1)))]);
     right_pk[((size_t)frame * h + y) * w + p] = best;
 }
 
 size_t wta_fused_partial_elems(const Geometry &g) {
     const int cols = fused_waves(g.D / 16) * (64 / (g.D / 16));
-    return (size_t)g.h * ((g.w + cols - 1) / cols) * (cols + g.D);
+    const int hpad = (g.h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
+    return (size_t)hpad * ((g.w + cols - 1) / cols) * (cols + g.D);
 }
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
