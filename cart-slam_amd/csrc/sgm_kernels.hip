@@ -546,9 +546,10 @@ __device__ __forceinline__ uint32_t uniq_threshold(uint32_t bc, float u) {
 template <int LPP>
 __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                                                   Geometry g, float uniq) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t s_lds[];  // [kWtaTileX][D]
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_lds[];  // [kWtaTileX][DP]
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int D = LPP * 16;
+    constexpr int DP = D + 8;                 // LDS row pitch in u16: 16 B of padding spread the pixels' rows over the banks
     constexpr int PPP = 256 / LPP;            // pixels per pass
     constexpr int NPASS = kWtaTileX / PPP;    // 1 (D=64), 2 (D=128), 4 (D=256)
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
                 sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
             }
         }
-        v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * D + d0);  // LDS tile in natural disparity order
+        v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * DP + d0);  // LDS tile in natural disparity order
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
         dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
         // packed argmin keys: S*16 + local disparity index
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
             if (x >= g.w) continue;
             const int bd = (int)(pk_res[pass] & 0xffffu), bc = (int)(pk_res[pass] >> 16);
             const int T = (int)uniq_threshold((uint32_t)bc, uniq);
-            const uint16_t *srow = s_lds + xl * D;
+            const uint16_t *srow = s_lds + xl * DP;
             const int l = bd > 0 ? srow[bd - 1] : 0x7fff, r = bd < D - 1 ? srow[bd + 1] : 0x7fff;
             const int tot_nbr = max(T - bc, 0) + max(T - l, 0) + max(T - r, 0);
             uint32_t out = kWtaInvalid;
@@ -628,14 +629,14 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
         const int xa = max(x0, p), xb = min(min(x0 + kWtaTileX, p + D), g.w);
         uint32_t best = 0xffffffffu;
         int x = xa;
-        const uint16_t *sp = s_lds + (x - x0) * D + (x - p);
-        for (; x + 3 < xb; x += 4, sp += 4 * (D + 1)) {
+        const uint16_t *sp = s_lds + (x - x0) * DP + (x - p);
+        for (; x + 3 < xb; x += 4, sp += 4 * (DP + 1)) {
             const uint32_t d = (uint32_t)(x - p);
-            const uint32_t k0 = ((uint32_t)sp[0] << 16) | d, k1 = ((uint32_t)sp[D + 1] << 16) | (d + 1);
-            const uint32_t k2 = ((uint32_t)sp[2 * (D + 1)] << 16) | (d + 2), k3 = ((uint32_t)sp[3 * (D + 1)] << 16) | (d + 3);
+            const uint32_t k0 = ((uint32_t)sp[0] << 16) | d, k1 = ((uint32_t)sp[DP + 1] << 16) | (d + 1);
+            const uint32_t k2 = ((uint32_t)sp[2 * (DP + 1)] << 16) | (d + 2), k3 = ((uint32_t)sp[3 * (DP + 1)] << 16) | (d + 3);
             best = min(min(best, min(k0, k1)), min(k2, k3));
         }
-        for (; x < xb; ++x, sp += D + 1) best = min(best, ((uint32_t)sp[0] << 16) | (uint32_t)(x - p));
+        for (; x < xb; ++x, sp += DP + 1) best = min(best, ((uint32_t)sp[0] << 16) | (uint32_t)(x - p));
         if (xa < xb) atomicMin(&right_pk[(size_t)frame * g.npx + (size_t)y * g.w + p], best);
     }
 }
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void wta_kernel(const uint8_t *slabs, uint16_t
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
-    const size_t lds = (size_t)kWtaTileX * g.D * sizeof(uint16_t);
+    const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
     switch (g.D) {
         case 64: hipLaunchKernelGGL(wta_kernel<4>, grid, block, lds, s, slabs, wta_l, right_pk, g, uniq); break;
         case 128: hipLaunchKernelGGL(wta_kernel<8>, grid, block, lds, s, slabs, wta_l, right_pk, g, uniq); break;
