@@ -707,7 +707,8 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     constexpr int WPB = fused_waves(LPP), NT = 64 * WPB;
     constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
     __shared__ uint32_t s_win[WPB][WN::BUF];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * D];
+    constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
+    __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * DP];
     constexpr int RB = 16;                       // rows buffered in LDS between two bursts (= kFusedRB; 32 rows cost an LDS-limited block per CU)
     __shared__ uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
         }
         load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
         uint16_t *tile = &s_tile[0][0];   // single buffer: every wave only touches the rows of its own pixels
-        v4u *dst = reinterpret_cast<v4u *>(tile + xl * D + d0);
+        v4u *dst = reinterpret_cast<v4u *>(tile + xl * DP + d0);
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
         dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
         // ---- left view: argmin + uniqueness (same arithmetic as wta_kernel)
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
         // deferred to the burst, where all lanes work on it.
         if (gl == 0) {
             const int bd = (int)(pk & 0xffffu), bc = (int)(pk >> 16);
-            const uint16_t *srow = tile + xl * D;
+            const uint16_t *srow = tile + xl * DP;
             const int l = bd > 0 ? srow[bd - 1] : 0x7fff, rr = bd < D - 1 ? srow[bd + 1] : 0x7fff;
             const int Ti = (int)T;
             const int tot_nbr = max(Ti - bc, 0) + max(Ti - l, 0) + max(Ti - rr, 0);
