@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * DP];
     constexpr int RB = 16;                       // rows buffered in LDS between two bursts (= kFusedRB; 32 rows cost an LDS-limited block per CU)
-    __shared__ uint32_t s_rmin[RB][NRP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
     __shared__ uint16_t s_thr[2048];             // uniqueness threshold by best cost (sums are <= 8 * 255)
     const Geometry &g = a.g;
@@ -915,14 +915,23 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
             const bool live = r < nrows && x0 + c < g.w && i0 + (int)threadIdx.x < RB * COLS;
             uint16_t *dst = live ? a.wta_l + (size_t)frame * g.npx + (size_t)(g.h - 1 - t0 - r) * g.w + x0 + c
                                  : reinterpret_cast<uint16_t *>(pbase + NR);   // the pad entry of the chunk's first row
-            *dst = (uint16_t)out;
+            if (!(CART_FUSED_ABLATE & 16)) *dst = (uint16_t)out;
         }
+        static_assert(RB * NRP % 4 == 0, "the right-view rows are copied 16 bytes per lane");
 #pragma unroll
-        for (int i0 = 0; i0 < RB * NRP; i0 += NT) {
-            const int i = min(i0 + (int)threadIdx.x, RB * NRP - 1);
-            const uint32_t v = (&s_rmin[0][0])[i];
-            (&s_rmin[0][0])[i] = 0xffffffffu;
-            pbase[i] = v;
+        for (int i0 = 0; i0 < RB * NRP / 4; i0 += NT) {
+            const int i = i0 + (int)threadIdx.x;
+            const bool live = i < RB * NRP / 4;   // excess lanes store ones into the last (never used) row of the block's area
+            v4u v = v4u{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (live) {
+                v4u *src = reinterpret_cast<v4u *>(&s_rmin[0][0]) + i;
+                const v4u t = *src;
+                *src = v;
+                v = t;
+            }
+            v4u *dst = live ? reinterpret_cast<v4u *>(pbase) + i
+                            : reinterpret_cast<v4u *>(a.partial + (((size_t)frame * nblk + blk + 1) * (size_t)hpad) * NRP) - 1;
+            if (!(CART_FUSED_ABLATE & 8)) *dst = v;
         }
         lds_barrier();
     };
