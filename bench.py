@@ -5,7 +5,7 @@
 
 One "step" = one pass of the whole hot path (disparity module: census -> 8-path SGM -> WTA ->
 medians/LR/range -> interpolate; plane module: vertical derivative + histogram -> plane parameters
--> classify -> connected components) over one batch of `--batch` synthetic 1242x375 stereo pairs
+-> classify -> connected components + component table) over one batch of `--batch` synthetic 1242x375 stereo pairs
 per GPU, D=128, inputs resident in HBM.  Frames shard by id across ranks (weak scaling); the only
 exchange is the all-gather of per-frame 256-bin histograms for the plane-parameter schedule.
 Prints ONE JSON line on rank 0.

@@ -237,6 +237,18 @@ class Engine:
                                              _stream_ptr()), "cart_plane_ccl")
         return ids, ncomp
 
+    def plane_ccl_stats(self, planes, ids, max_components=4096):
+        """-> (table int32 [n, max_components, 7] rows {id, label, area, x0, y0, x1, y1} in ascending id order,
+        n_components int32 [n]) -- frames with more components keep their first max_components rows."""
+        import torch
+        n, p, s, fs = _geom(planes, 1)
+        _, ip, is_, ifs = _geom(ids, 1)
+        table = torch.empty((n, max_components, 7), dtype=torch.int32, device=planes.device)  # rows >= n_components stay undefined
+        ncomp = torch.empty((n,), dtype=torch.int32, device=planes.device)
+        self._check(self._lib.cart_plane_ccl_stats(self._h, n, p, s, fs, ip, is_, ifs, C.c_void_p(table.data_ptr()), int(max_components),
+                                                   C.c_void_p(ncomp.data_ptr()), _stream_ptr()), "cart_plane_ccl_stats")
+        return table, ncomp
+
     # ---- diagnostics ----
     def debug_read(self, what, frame_slot=0):
         lib = self._lib

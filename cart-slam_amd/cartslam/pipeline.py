@@ -61,13 +61,14 @@ class StereoPipeline:
     (PlaneParameterSchedule + cart_find_plane_params), which is what the reference's module does per frame."""
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
-                 with_ccl=True, group=None, device_schedule=True, overlap=False):
+                 with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
         self.schedule = PlaneParameterSchedule(provider, static_params, update_interval, reset_interval)
         self.dev_schedule = DevicePlaneSchedule(engine, provider, static_params, update_interval, reset_interval) if device_schedule else None
         self.with_ccl = with_ccl
+        self.max_components = max_components   # rows of the per-frame component table (id, label, area, bbox)
         self.group = group
         self.world = 1
         self.rank = 0
@@ -125,6 +126,7 @@ class StereoPipeline:
             out = dict(disparity=disp, planes=planes, params=mine)
             if self.with_ccl:
                 out["ids"], out["n_components"] = eng.plane_ccl(planes)
+                out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
             return out
         if self.schedule.provider == "static":
             per_frame = [self.schedule.params] * n
@@ -146,4 +148,5 @@ class StereoPipeline:
         out = dict(disparity=disp, planes=planes, params=per_frame)
         if self.with_ccl:
             out["ids"], out["n_components"] = eng.plane_ccl(planes)
+            out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
         return out

@@ -67,6 +67,7 @@ struct cart_engine {
     int32_t *ccl_work = nullptr;
     uint32_t *rv_partial = nullptr; // [max_inflight][wta_fused_partial_elems], allocated by the first fused batch
     uint8_t *flow_ws = nullptr;     // [max_inflight][flow_ws_bytes]: gray x2, census x2, scratch; first cart_optical_flow allocates
+    int32_t *ccl_stats_ws = nullptr; // [max_inflight][npx + h]: root -> table row, per-row root bases; first cart_plane_ccl_stats allocates
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
@@ -298,7 +299,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
@@ -559,6 +560,34 @@ int cart_plane_ccl(cart_engine *e, int n_frames, const uint8_t *planes, size_t p
     hipError_t err = hipGetLastError();
     release(l);
     if (err != hipSuccess) return fail(std::string("ccl failed: ") + hipGetErrorString(err));
+    return 0;
+}
+
+int cart_plane_ccl_stats(cart_engine *e, int n_frames, const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
+                         const int32_t *ids, size_t ids_step, size_t ids_frame_stride, cart_component *table, int max_components,
+                         int32_t *n_components, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!planes || !ids || !table) return fail("NULL pointer");
+    if (max_components < 1) return fail("max_components must be positive");
+    const Geometry &g = e->g;
+    if (planes_step < (size_t)g.w || ids_step < (size_t)g.w * 4 || (ids_step & 3) || (ids_frame_stride & 3)) return fail("bad step");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    const size_t per_slot = g.npx + (size_t)g.h;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->ccl_stats_ws) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->ccl_stats_ws), e->slots.size() * per_slot * sizeof(int32_t)));
+    }
+    Lease l;
+    if (acquire(e, n_frames, stream, &l)) return -1;
+    // slots of a lease are contiguous: [slot][npx] root->row maps first, then [slot][h] row bases
+    int32_t *slot_map = e->ccl_stats_ws + (size_t)l.s0 * per_slot;
+    int32_t *rowwork = slot_map + (size_t)n_frames * g.npx;
+    launch_ccl_stats(planes, planes_step, planes_frame_stride, ids, ids_step, ids_frame_stride, rowwork, slot_map, table, max_components,
+                     n_components, g.w, g.h, n_frames, stream);
+    hipError_t err = hipGetLastError();
+    release(l);
+    if (err != hipSuccess) return fail(std::string("ccl stats failed: ") + hipGetErrorString(err));
     return 0;
 }
 

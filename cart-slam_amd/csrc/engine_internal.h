@@ -82,6 +82,10 @@ void launch_classify(const int16_t *deriv, size_t step, size_t fs, const Classif
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
                 int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
 
+// component table (S12): rowwork = [n_frames][h] int32, slot = [n_frames][npx] int32 (only root positions are written/read)
+void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *rowwork,
+                      int32_t *slot, cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
+
 void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params_dev, int params_stride,
                          uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s);
 struct ScheduleState {   // device resident

@@ -441,6 +441,149 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
 }
 
-int kernel_count() { return 38; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 12 + superpixel_kernels 8 + flow 3
+// ------------------------------------------------------------------ component table (oracle S12: id, label, area, bbox)
+// Roots are the pixels whose id is their own linear index, so raster order = ascending id.  (1) roots per row,
+// (2) exclusive scan over the rows (one block per frame), (3) ordered rank of every root -> slot[root] and the
+// initialised table row, (4) every 64-pixel piece of a horizontal run adds its length / extent to its component's row
+// with a handful of atomics (pieces come from one wave ballot, no serial walks).
+__global__ __launch_bounds__(256) void ccl_root_count_kernel(const int32_t *ids, size_t istep, size_t ifs, int32_t *rowcount, int w, int h) {
+    __shared__ int tot[4];
+    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int32_t *row = row_ptr(ids, ifs, istep, frame, y);
+    int c = 0;
+    for (int x = tid; x < w; x += 256) c += row[x] == y * w + x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((tid & 63) == 0) tot[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) rowcount[(size_t)frame * h + y] = tot[0] + tot[1] + tot[2] + tot[3];
+}
+
+__global__ __launch_bounds__(256) void ccl_root_scan_kernel(int32_t *rowcount, int32_t *ncomp, int h) {  // in place: counts -> exclusive bases
+    __shared__ int part[256];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    int32_t *rc = rowcount + (size_t)frame * h;
+    const int per = (h + 255) / 256, y0 = tid * per, y1 = min(y0 + per, h);
+    int s = 0;
+    for (int y = y0; y < y1; ++y) s += rc[y];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        if (ncomp) ncomp[frame] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int y = y0; y < y1; ++y) { const int v = rc[y]; rc[y] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void ccl_root_init_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep,
+                                                            size_t ifs, const int32_t *rowbase, int32_t *slot, cart_component *table,
+                                                            int max_components, int w, int h, size_t npx) {
+    __shared__ int wave_tot[4];
+    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int32_t *row = row_ptr(ids, ifs, istep, frame, y);
+    const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
+    int carry = rowbase[(size_t)frame * h + y];
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + tid;
+        const bool root = x < w && row[x] == y * w + x;
+        const unsigned long long m = __ballot(root);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wid] = __popcll(m);
+        __syncthreads();
+        int prefix = carry, all = carry;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < wid) prefix += wave_tot[k];
+            all += wave_tot[k];
+        }
+        if (root) {
+            const int r = prefix + before;
+            slot[(size_t)frame * npx + (size_t)y * w + x] = r;
+            if (r < max_components) {
+                cart_component c;
+                c.id = y * w + x; c.label = prow[x]; c.area = 0; c.x0 = w; c.y0 = h; c.x1 = -1; c.y1 = -1;
+                table[(size_t)frame * max_components + r] = c;
+            }
+        }
+        carry = all;
+        __syncthreads();
+    }
+}
+
+// Tile = 64 columns x 16 rows per block.  The pieces of a tile are first merged per component in a small LDS hash
+// (a road-sized component otherwise receives ~7 500 x 5 same-address global atomics per frame, which serialise in L2:
+// measured 1 ms per 16-frame batch); one set of global atomics per (tile, component) remains.  A full hash falls back
+// to direct global atomics.
+__global__ __launch_bounds__(256) void ccl_stats_accum_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep,
+                                                              size_t ifs, const int32_t *slot, cart_component *table, int max_components,
+                                                              int w, int h, size_t npx) {
+    constexpr int HS = 128;
+    __shared__ int hkey[HS], harea[HS], hx0[HS], hy0[HS], hx1[HS], hy1[HS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, frame = blockIdx.z;
+    if (tid < HS) { hkey[tid] = -1; harea[tid] = 0; hx0[tid] = w; hy0[tid] = h; hx1[tid] = -1; hy1[tid] = -1; }
+    __syncthreads();
+    const int x = blockIdx.x * 64 + lane;
+    cart_component *tab = table + (size_t)frame * max_components;
+    for (int k = 0; k < 4; ++k) {
+        const int y = blockIdx.y * 16 + wid * 4 + k;   // wave-uniform
+        if (y >= h) break;
+        const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
+        const int c = x < w ? prow[x] : 255;
+        const bool in = c <= 1;
+        const int cp = __shfl_up(c, 1);
+        const bool head = in && (lane == 0 || cp != c);   // a piece starts at lane 0 of the wave or where the label changes
+        const unsigned long long heads = __ballot(head), ins = __ballot(in);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : (~0ull << (lane + 1));
+            const unsigned long long stop = (heads | ~ins) & later;   // next head or first non-member lane
+            const int end_lane = stop ? __ffsll((long long)stop) - 2 : 63;
+            const int len = end_lane - lane + 1;
+            const int id = row_ptr(ids, ifs, istep, frame, y)[x];
+            const int r = slot[(size_t)frame * npx + id];
+            if (r < max_components) {
+                int hpos = (int)(((unsigned)r * 2654435761u) >> 25);   // 7 bits
+                bool done = false;
+                for (int probe = 0; probe < 8 && !done; ++probe, hpos = (hpos + 1) & (HS - 1)) {
+                    const int old = atomicCAS(&hkey[hpos], -1, r);
+                    if (old == -1 || old == r) {
+                        atomicAdd(&harea[hpos], len);
+                        atomicMin(&hx0[hpos], x); atomicMax(&hx1[hpos], x + len - 1);
+                        atomicMin(&hy0[hpos], y); atomicMax(&hy1[hpos], y);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    cart_component *e = tab + r;
+                    atomicAdd(&e->area, len);
+                    atomicMin(&e->x0, x); atomicMax(&e->x1, x + len - 1);
+                    atomicMin(&e->y0, y); atomicMax(&e->y1, y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < HS && hkey[tid] >= 0) {
+        cart_component *e = tab + hkey[tid];
+        atomicAdd(&e->area, harea[tid]);
+        atomicMin(&e->x0, hx0[tid]); atomicMax(&e->x1, hx1[tid]);
+        atomicMin(&e->y0, hy0[tid]); atomicMax(&e->y1, hy1[tid]);
+    }
+}
+
+void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *rowwork,
+                      int32_t *slot, cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
+    const size_t npx = (size_t)w * h;
+    hipLaunchKernelGGL(ccl_root_count_kernel, dim3(h, n_frames), dim3(256), 0, s, ids, istep, ifs, rowwork, w, h);
+    hipLaunchKernelGGL(ccl_root_scan_kernel, dim3(n_frames), dim3(256), 0, s, rowwork, ncomp, h);
+    hipLaunchKernelGGL(ccl_root_init_kernel, dim3(h, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs, (const int32_t *)rowwork, slot,
+                       table, max_components, w, h, npx);
+    hipLaunchKernelGGL(ccl_stats_accum_kernel, dim3((w + 63) / 64, (h + 15) / 16, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs,
+                       (const int32_t *)slot, table, max_components, w, h, npx);
+}
+
+int kernel_count() { return 42; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 16 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

@@ -18,6 +18,9 @@
 #define CARTSLAM_KEY_DISPARITY_DERIVATIVE_HIST "disp_derivative_histogram"
 #define CARTSLAM_KEY_OPTFLOW "optflow"  // include/modules/optflow.hpp
 #define CARTSLAM_KEY_PLANE_COMPONENTS "plane_components"  // new: connected-component ids (no reference counterpart)
+#define CARTSLAM_KEY_PLANE_COMPONENT_TABLE "plane_component_table"  // new: CV_32SC1 [4096 x 7]: {id, label, area, x0, y0, x1, y1} per row
+#define CARTSLAM_KEY_PLANE_COMPONENT_COUNT "plane_component_count"  // new: int32, number of components (rows beyond 4096 are dropped)
+#define CARTSLAM_PLANE_COMPONENT_TABLE_ROWS 4096
 #define CARTSLAM_PLANE_COUNT 3
 #define CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT 3
 

@@ -45,7 +45,8 @@ int main(int argc, char **argv) {
         }
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
-                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS, CARTSLAM_KEY_OPTFLOW};
+                                  CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS, CARTSLAM_KEY_OPTFLOW,
+                                  CARTSLAM_KEY_PLANE_COMPONENT_TABLE, CARTSLAM_KEY_PLANE_COMPONENT_COUNT};
             for (int id = 1; id <= frames; ++id) {
                 std::shared_ptr<cart::SystemRunData> run;
                 try { run = system->getRunById((uint32_t)id); } catch (const std::exception &) { continue; }  // evicted (retention ring)

@@ -147,7 +147,11 @@ DisparityPlaneSegmentationModule::DisparityPlaneSegmentationModule(std::shared_p
     }
     this->providesData.push_back(CARTSLAM_KEY_PLANES);
     if (useTemporalSmoothing) this->providesData.push_back(CARTSLAM_KEY_PLANES_UNSMOOTHED);
-    if (labelComponents) this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENTS);
+    if (labelComponents) {
+        this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENTS);
+        this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENT_TABLE);
+        this->providesData.push_back(CARTSLAM_KEY_PLANE_COMPONENT_COUNT);
+    }
 }
 
 DisparityPlaneSegmentationModule::~DisparityPlaneSegmentationModule() {
@@ -213,11 +217,20 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
                                      smoothed->ptr<uint8_t>(), smoothed->step, stream.s) != 0)
             eng->fail("cart_plane_temporal_vote");
     }
-    std::shared_ptr<image_t> components;
+    std::shared_ptr<image_t> components, componentTable, componentCount;
     if (labelComponents) {
         components = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_32SC1);
         if (cart_plane_ccl(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0, nullptr, stream.s) != 0)
             eng->fail("cart_plane_ccl");
+        componentTable = std::make_shared<image_t>(CARTSLAM_PLANE_COMPONENT_TABLE_ROWS, 7, CV_32SC1);
+        componentCount = std::make_shared<image_t>(1, 1, CV_32SC1);
+        static_assert(sizeof(cart_component) == 7 * sizeof(int32_t), "table rows are 7 x int32");
+        if (componentTable->step != 7 * sizeof(int32_t)) {  // DeviceImage pads rows to 256 B: the table wants tight rows
+            componentTable = std::make_shared<image_t>(1, CARTSLAM_PLANE_COMPONENT_TABLE_ROWS * 7, CV_32SC1);
+        }
+        if (cart_plane_ccl_stats(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0,
+                                 componentTable->ptr<cart_component>(), CARTSLAM_PLANE_COMPONENT_TABLE_ROWS, componentCount->ptr<int32_t>(), stream.s) != 0)
+            eng->fail("cart_plane_ccl_stats");
     }
     stream.wait();
     system_data_t out;
@@ -227,7 +240,11 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
     } else {
         out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANES), std::shared_ptr<void>(planes)));
     }
-    if (labelComponents) out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
+    if (labelComponents) {
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENTS), std::shared_ptr<void>(components)));
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENT_TABLE), std::shared_ptr<void>(componentTable)));
+        out.push_back(std::make_pair(std::string(CARTSLAM_KEY_PLANE_COMPONENT_COUNT), std::shared_ptr<void>(componentCount)));
+    }
     return out;
 }
 

@@ -132,6 +132,20 @@ int cart_plane_ccl(cart_engine *engine, int n_frames,
                    int32_t *ids, size_t ids_step, size_t ids_frame_stride,
                    int32_t *n_components, void *stream);
 
+/* Component table of a label map and its ids (same stage, SURVEY 8a-11 "per-component {label, area, bbox}"): one entry per
+ * component in ascending id order, bounding box inclusive.  `table` = device [n_frames][max_components]; a frame with more
+ * components gets its first max_components entries, n_components (device, may be NULL) always holds the true count. */
+typedef struct cart_component {
+    int32_t id;            /* smallest linear index y*width+x of the component */
+    int32_t label;         /* CART_PLANE_HORIZONTAL or CART_PLANE_VERTICAL */
+    int32_t area;          /* pixels */
+    int32_t x0, y0, x1, y1;
+} cart_component;
+int cart_plane_ccl_stats(cart_engine *engine, int n_frames,
+                         const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
+                         const int32_t *ids, size_t ids_step, size_t ids_frame_stride,
+                         cart_component *table, int max_components, int32_t *n_components, void *stream);
+
 /* replaces: HistogramPeakPlaneParameterProvider::updatePlaneParameters (planeseg.cu:405-458) +
  * util::findPeaks (src/utils/peaks.cpp:12-72).  HOST function on a host histogram.  Returns 1 if
  * *inout was updated, 0 on the reference's early-outs (parameters kept), <0 on error. */

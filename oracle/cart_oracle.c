@@ -495,3 +495,35 @@ int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids) {
         if (planes[i] <= 1) ids[i] = uf_find(ids, (int)i);
     return ncomp;
 }
+
+/* a-11 (S12): the component table.  Roots are the pixels whose id equals their own linear index, so a raster scan meets
+ * the components in ascending id order. */
+int cart_oracle_ccl_stats(const uint8_t *planes, const int32_t *ids, int w, int h, int32_t *table, int max_components) {
+    const size_t npx = (size_t)w * h;
+    int32_t *slot = (int32_t *)malloc(npx * sizeof(int32_t));  /* root index -> table row */
+    int n = 0;
+    for (size_t i = 0; i < npx; ++i) {
+        slot[i] = -1;
+        if (ids[i] == (int32_t)i) {
+            if (n < max_components) {
+                int32_t *e = table + (size_t)n * 7;
+                e[0] = (int32_t)i; e[1] = planes[i]; e[2] = 0; e[3] = w; e[4] = h; e[5] = -1; e[6] = -1;
+                slot[i] = n;
+            }
+            ++n;
+        }
+    }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int32_t id = ids[(size_t)y * w + x];
+            if (id < 0 || slot[id] < 0) continue;
+            int32_t *e = table + (size_t)slot[id] * 7;
+            e[2] += 1;
+            if (x < e[3]) e[3] = x;
+            if (y < e[4]) e[4] = y;
+            if (x > e[5]) e[5] = x;
+            if (y > e[6]) e[6] = y;
+        }
+    free(slot);
+    return n;
+}

@@ -51,6 +51,8 @@
  *  S12 CCL      (no reference counterpart) 4-connected components over the plane
  *                 label map for labels {0,1}; component id = smallest linear index
  *                 y*W+x in the component; label-2 (UNKNOWN) pixels get -1.
+ *                 Component table: one entry {id, label, area, x0, y0, x1, y1} (inclusive bounding
+ *                 box) per component, ordered by ascending id.
  *  S13 superpixels (contour relaxation; reference: src/modules/superpixels.cu and superpixels/contourrelaxation/): the reference's
  *                 result depends on racy featureCost refreshes, nvcc FMA contraction and CUDA's log(); the spec is the
  *                 race-free intent: per iteration EVERY pixel picks, from the unique labels of its in-image 3x3
@@ -167,6 +169,10 @@ void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float 
 
 /* a-11 (S12). Returns the number of components. */
 int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids);
+
+/* a-11 (S12) component table from the label map and its ids: 7 int32 per component {id, label, area, x0, y0, x1, y1},
+ * ascending id; writes at most max_components entries, returns the number of components. */
+int cart_oracle_ccl_stats(const uint8_t *planes, const int32_t *ids, int w, int h, int32_t *table, int max_components);
 
 /* ---- superpixels + superpixel plane labelling ------------------------------------------------- */
 

@@ -185,6 +185,16 @@ def ccl(planes):
     return ids, n
 
 
+def ccl_stats(planes, ids, max_components=None):
+    """-> int32 [n,7] rows {id, label, area, x0, y0, x1, y1} in ascending id order (S12)."""
+    h, w = planes.shape
+    cap = int(max_components if max_components is not None else h * w)
+    table = np.zeros((cap, 7), np.int32)
+    lib().cart_oracle_ccl_stats.restype = C.c_int
+    n = lib().cart_oracle_ccl_stats(_p(np.ascontiguousarray(planes, np.uint8)), _p(np.ascontiguousarray(ids, np.int32)), w, h, _p(table), cap)
+    return table[:min(n, cap)], n
+
+
 def reproject_depth(disp, Q):
     h, w = disp.shape
     Q = np.ascontiguousarray(Q, np.float32).reshape(16)

@@ -340,6 +340,7 @@ def _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule, o
     outs = [{k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in o.items()} for o in raw]
     disp = np.concatenate([o["disparity"] for o in outs]); planes = np.concatenate([o["planes"] for o in outs])
     ids = np.concatenate([o["ids"] for o in outs]); ncomp = np.concatenate([o["n_components"] for o in outs])
+    comps = np.concatenate([o["components"] for o in outs])
     cum = np.zeros(256, np.int64)
     params = (0, 0, 0, 0, 0, 0)
     for f in range(n):
@@ -357,6 +358,8 @@ def _pipeline_case(torch, eng, ls, rs, w, h, D, P, n, ui, ri, device_schedule, o
         assert (planes[f] == ep).all(), f"planes frame {fid}"
         eids, en = O.ccl(ep)
         assert (ids[f] == eids).all() and ncomp[f] == en, f"ccl frame {fid}"
+        et, _ = O.ccl_stats(ep, eids, max_components=4096)
+        assert (comps[f][:len(et)] == et).all(), f"component table frame {fid}"
 
 
 def test_device_plane_schedule_matches_host_restatement(torch_cuda):
@@ -645,4 +648,34 @@ def test_optical_flow_block_matching(torch_cuda):
     assert ((inner[..., 0] == -5 * 32) & (inner[..., 1] == 3 * 32)).mean() > 0.999
     with pytest.raises(Exception):
         eng.optical_flow(dev(torch, cur), dev(torch, prev), 17, 2)
+    eng.close()
+
+
+def test_ccl_component_table(torch_cuda):
+    """cart_plane_ccl_stats (per-component label, area, bounding box) against the oracle: random maps,
+    hard shapes, a batch, runs longer than a wave, and truncation at max_components."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    w, h = 300, 70
+    eng = make_engine(w, h, 0, 0, inflight=3)
+    maps = [rng.integers(0, 3, (h, w)).astype(np.uint8),
+            np.kron(rng.integers(0, 3, (h // 7, w // 10)), np.ones((7, 10), int)).astype(np.uint8),
+            np.zeros((h, w), np.uint8)]
+    maps[2][::2, :] = 1                      # full-width runs (many 64-pixel pieces per run)
+    maps[2][:, 150] = 0                      # ... joined by one column
+    pl = dev(torch, np.stack(maps))
+    ids, n = eng.plane_ccl(pl)
+    table, n2 = eng.plane_ccl_stats(pl, ids, max_components=8192)
+    assert (n.cpu().numpy() == n2.cpu().numpy()).all()
+    for f in range(3):
+        eids, en = O.ccl(maps[f])
+        et, en2 = O.ccl_stats(maps[f], eids)
+        assert en == en2 == int(n2[f])
+        got = table[f, :en].cpu().numpy()
+        assert (got == et).all(), f"frame {f}: {int((got != et).any(axis=1).sum())} rows differ"
+        assert got[:, 2].sum() == (maps[f] < 2).sum()
+    # truncation keeps the first rows and still reports the true count
+    table_s, n3 = eng.plane_ccl_stats(pl[:1], ids[:1], max_components=5)
+    et, en = O.ccl_stats(maps[0], O.ccl(maps[0])[0], max_components=5)
+    assert int(n3[0]) == en and (table_s[0].cpu().numpy() == et).all()
     eng.close()

@@ -123,8 +123,12 @@ def test_frame_loop_matches_oracle(tmp_path, channels):
             _, params = O.histogram_peak_params(h32, params)
         ep = O.classify(pd, params)
         assert (load(tmp, fid, "planes", np.uint8, (h, w)) == ep).all(), f"planes frame {fid}"
-        eids, _ = O.ccl(ep)
+        eids, en = O.ccl(ep)
         assert (load(tmp, fid, "plane_components", np.int32, (h, w)) == eids).all()
+        et, _ = O.ccl_stats(ep, eids, max_components=4096)
+        assert int(np.fromfile(os.path.join(tmp, "dump", f"{fid}_plane_component_count.bin"), np.int32)[0]) == en
+        got = np.fromfile(os.path.join(tmp, "dump", f"{fid}_plane_component_table.bin"), np.int32).reshape(4096, 7)
+        assert (got[:len(et)] == et).all(), f"component table frame {fid}"
 
 
 @pytest.mark.gpu

@@ -307,3 +307,16 @@ def test_block_flow_matches_numpy_and_recovers_shifts():
     assert (O.block_flow(cur, cur, 3, 2) == 0).all()
     flat = np.full((h, w), 90, np.uint8)
     assert (O.block_flow(flat, flat, 3, 2) == 0).all()
+
+
+def test_ccl_component_table_known_answers():
+    pl = np.full((6, 8), 2, np.uint8)
+    pl[1:3, 1:4] = 0          # a 2x3 horizontal-plane block
+    pl[4, 2:7] = 1            # a 1x5 vertical-plane strip
+    pl[0, 7] = 1              # a single pixel
+    ids, n = O.ccl(pl)
+    table, n2 = O.ccl_stats(pl, ids)
+    assert n == n2 == 3
+    assert table.tolist() == [[7, 1, 1, 7, 0, 7, 0], [9, 0, 6, 1, 1, 3, 2], [34, 1, 5, 2, 4, 6, 4]]
+    t2, n3 = O.ccl_stats(pl, ids, max_components=2)
+    assert n3 == 3 and t2.tolist() == table[:2].tolist()
