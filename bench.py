@@ -143,6 +143,24 @@ def main():
     elapsed = time.perf_counter() - t0
     stages, ncalls = eng.collect_timing()
     eng.set_timing(False)
+    copy_gbps = None
+    if rank == 0:
+        # achievable-copy ceiling of THIS box ("quote both fractions"): device-to-device copy of 2 GiB,
+        # bytes read + bytes written per second
+        try:
+            src = torch.empty(1 << 31, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
+            src.fill_(1)
+            for _ in range(2):
+                dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            c1.record(); torch.cuda.synchronize()
+            copy_gbps = 2 * src.numel() * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbps = None
     pcie = None
     if world == 1 and not args.no_pcie:
         # Informational (never `value`): the same step when the caller hands over HOST buffers -- H2D of the 16 pairs
@@ -214,7 +232,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": agg_bytes, "frames_per_launch": fpl, "launch_ms": round(agg_ms, 4),
-                         "launches_timed": ncalls},
+                         "launches_timed": ncalls,
+                         "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                         "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None},
             "stages_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
