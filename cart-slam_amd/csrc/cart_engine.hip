@@ -38,6 +38,7 @@ struct Slot {
     int owner = -1;                     // ... every slot of the lease points at that slot
     hipStream_t last_stream = nullptr;
     bool used = false;
+    unsigned long long released_seq = 0;  // order of the last release (guarded by mu)
 };
 
 constexpr int kMaxTimings = 8;
@@ -75,6 +76,7 @@ struct cart_engine {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
+    unsigned long long release_counter = 0;    // guarded by mu
     int chunk_frames = 16;          // frames per launch sequence inside one batched call
     bool post_only = false;         // no SGM workspaces (num_disparities == 0)
     bool timing = false;
@@ -96,22 +98,26 @@ int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
     std::unique_lock<std::mutex> lk(e->mu);
     int s0 = -1;
     for (;;) {
-        // First fit, preferring a range whose slots were last used on THIS stream (or never): reusing another stream's
-        // slots costs an event wait that serialises two pipelined streams for no reason.
+        // Preference: a free range last used on THIS stream (or never): no event wait at all; otherwise the free range that
+        // was released longest ago -- a first fit would hand a pipelined caller the slots of its previous batch, whose tail
+        // may still be queued on another stream, and serialise the two streams.
         const int total = (int)e->slots.size();
-        int fallback = -1;
+        int oldest = -1;
+        unsigned long long oldest_seq = ~0ull;
         for (int i = 0; i + n <= total && s0 < 0; ++i) {
             bool ok = true, same = true;
+            unsigned long long seq = 0;
             for (int k = 0; k < n; ++k) {
                 const Slot &sl = e->slots[i + k];
                 if (sl.busy) { ok = false; i += k; break; }
                 same &= !sl.used || sl.last_stream == stream;
+                seq = std::max(seq, sl.released_seq);
             }
             if (!ok) continue;
             if (same) s0 = i;
-            else if (fallback < 0) fallback = i;
+            else if (seq < oldest_seq) { oldest_seq = seq; oldest = i; }
         }
-        if (s0 < 0) s0 = fallback;
+        if (s0 < 0) s0 = oldest;
         if (s0 >= 0) break;
         e->cv.wait(lk);
     }
@@ -144,7 +150,8 @@ void release(const Lease &l) {
     }
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        for (int k = 0; k < l.n; ++k) e->slots[l.s0 + k].busy = false;
+        const unsigned long long seq = ++e->release_counter;
+        for (int k = 0; k < l.n; ++k) { e->slots[l.s0 + k].busy = false; e->slots[l.s0 + k].released_seq = seq; }
     }
     e->cv.notify_all();
 }
@@ -715,6 +722,7 @@ struct cart_superpixels {
     hipEvent_t done = nullptr;   // orders successive calls that arrive on different streams
     hipStream_t last_stream = nullptr;
     bool used = false;
+    unsigned long long released_seq = 0;  // order of the last release (guarded by mu)
 };
 
 namespace {
