@@ -330,9 +330,15 @@ void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int
 // Parent links only ever decrease (atomicMin) and always point inside the component, so a stale
 // read (per-XCD L2s are not coherent inside a launch) can only lengthen a walk, never break it;
 // later passes run in later launches and therefore see every link.
+// find with path halving: every visited node is re-linked to its grandparent.  A link only ever moves to a smaller index
+// of the same component, so a stale read elsewhere merely walks the old (still valid) path.
 __device__ __forceinline__ int ccl_find(int32_t *L, int i) {
     int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (p != i) { i = p; p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    while (p != i) {
+        const int gp = __hip_atomic_load(&L[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) atomicMin(&L[i], gp);
+        i = p; p = gp;
+    }
     return i;
 }
 
@@ -513,23 +519,23 @@ __global__ __launch_bounds__(256) void ccl_root_init_kernel(const uint8_t *plane
     }
 }
 
-// Tile = 64 columns x 16 rows per block.  The pieces of a tile are first merged per component in a small LDS hash
-// (a road-sized component otherwise receives ~7 500 x 5 same-address global atomics per frame, which serialise in L2:
-// measured 1 ms per 16-frame batch); one set of global atomics per (tile, component) remains.  A full hash falls back
-// to direct global atomics.
+// One block per 64 x 64 tile (the 4 waves interleave its rows).  The pieces of the tile are first merged per component in
+// an LDS hash; one set of global atomics per (tile, component) remains -- a road-sized component otherwise receives
+// thousands of same-address global atomics per frame, which serialise in L2 (1 ms per 16-frame batch with one atomic set
+// per piece; whole-height stripes have too few blocks: 107 us).  A full hash falls back to direct atomics.
 __global__ __launch_bounds__(256) void ccl_stats_accum_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep,
                                                               size_t ifs, const int32_t *slot, cart_component *table, int max_components,
                                                               int w, int h, size_t npx) {
-    constexpr int HS = 128;
+    constexpr int HS = 512;
     __shared__ int hkey[HS], harea[HS], hx0[HS], hy0[HS], hx1[HS], hy1[HS];
+    constexpr int TR = 64;   // tile rows
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, frame = blockIdx.z;
-    if (tid < HS) { hkey[tid] = -1; harea[tid] = 0; hx0[tid] = w; hy0[tid] = h; hx1[tid] = -1; hy1[tid] = -1; }
+    for (int i = tid; i < HS; i += 256) { hkey[i] = -1; harea[i] = 0; hx0[i] = w; hy0[i] = h; hx1[i] = -1; hy1[i] = -1; }
     __syncthreads();
     const int x = blockIdx.x * 64 + lane;
     cart_component *tab = table + (size_t)frame * max_components;
-    for (int k = 0; k < 4; ++k) {
-        const int y = blockIdx.y * 16 + wid * 4 + k;   // wave-uniform
-        if (y >= h) break;
+    const int yend = min((int)(blockIdx.y + 1) * TR, h);
+    for (int y = blockIdx.y * TR + wid; y < yend; y += 4) {   // wave-uniform
         const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
         const int c = x < w ? prow[x] : 255;
         const bool in = c <= 1;
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(256) void ccl_stats_accum_kernel(const uint8_t *pla
             const int id = row_ptr(ids, ifs, istep, frame, y)[x];
             const int r = slot[(size_t)frame * npx + id];
             if (r < max_components) {
-                int hpos = (int)(((unsigned)r * 2654435761u) >> 25);   // 7 bits
+                int hpos = (int)(((unsigned)r * 2654435761u) >> 23);   // 9 bits
                 bool done = false;
                 for (int probe = 0; probe < 8 && !done; ++probe, hpos = (hpos + 1) & (HS - 1)) {
                     const int old = atomicCAS(&hkey[hpos], -1, r);
@@ -565,12 +571,13 @@ __global__ __launch_bounds__(256) void ccl_stats_accum_kernel(const uint8_t *pla
         }
     }
     __syncthreads();
-    if (tid < HS && hkey[tid] >= 0) {
-        cart_component *e = tab + hkey[tid];
-        atomicAdd(&e->area, harea[tid]);
-        atomicMin(&e->x0, hx0[tid]); atomicMax(&e->x1, hx1[tid]);
-        atomicMin(&e->y0, hy0[tid]); atomicMax(&e->y1, hy1[tid]);
-    }
+    for (int i = tid; i < HS; i += 256)
+        if (hkey[i] >= 0) {
+            cart_component *e = tab + hkey[i];
+            atomicAdd(&e->area, harea[i]);
+            atomicMin(&e->x0, hx0[i]); atomicMax(&e->x1, hx1[i]);
+            atomicMin(&e->y0, hy0[i]); atomicMax(&e->y1, hy1[i]);
+        }
 }
 
 void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *rowwork,
@@ -580,7 +587,7 @@ void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int
     hipLaunchKernelGGL(ccl_root_scan_kernel, dim3(n_frames), dim3(256), 0, s, rowwork, ncomp, h);
     hipLaunchKernelGGL(ccl_root_init_kernel, dim3(h, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs, (const int32_t *)rowwork, slot,
                        table, max_components, w, h, npx);
-    hipLaunchKernelGGL(ccl_stats_accum_kernel, dim3((w + 63) / 64, (h + 15) / 16, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs,
+    hipLaunchKernelGGL(ccl_stats_accum_kernel, dim3((w + 63) / 64, (h + 63) / 64, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs,
                        (const int32_t *)slot, table, max_components, w, h, npx);
 }
 
