@@ -47,9 +47,47 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const int16_t *src, si
     row_ptr(dst, dst_fs, dst_step, frame, y)[x] = ((unsigned)count > min_count) ? (int16_t)(sum / count) : (int16_t)INVALID;
 }
 
+// radius 2 (3x3 window, the configured smoothing of the reference's KITTI setups): four adjacent pixels per thread share
+// their six window columns -- per column the sum and count of the valid values of the three rows, then three columns per
+// output.  sum / count (count <= 9, |sum| < 2^24) is a float division truncated, which is exact here.
+__global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
+                                                             size_t dst_fs, int w, int h, int min_disp16, int max_disp) {
+    const int xb = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (xb >= w || y >= h) return;
+    int csum[6], ccnt[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { csum[c] = 0; ccnt[c] = 0; }
+#pragma unroll
+    for (int l = -1; l <= 1; ++l) {
+        const int yy = y + l;
+        if (yy < 0 || yy >= h) continue;
+        const int16_t *row = row_ptr(src, src_fs, src_step, frame, yy);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int xx = xb - 1 + c;
+            if (xx < 0 || xx >= w) continue;
+            const int v = row[xx];
+            if (v > min_disp16 && v < max_disp) { csum[c] += v; ++ccnt[c]; }
+        }
+    }
+    int16_t *orow = row_ptr(dst, dst_fs, dst_step, frame, y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (xb + i >= w) break;
+        const int sum = csum[i] + csum[i + 1] + csum[i + 2], count = ccnt[i] + ccnt[i + 1] + ccnt[i + 2];
+        // interpolation.cu:33: count > r*r + 1 = 5
+        orow[xb + i] = count > 5 ? (int16_t)(int)((float)sum / (float)count) : (int16_t)INVALID;
+    }
+}
+
 void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
                         size_t dst_fs, int w, int h, int radius, int min_disp16, int max_disp, int n_frames,
                         hipStream_t s) {
+    if (radius == 2 && min_disp16 > -(1 << 20) && max_disp < (1 << 20)) {
+        dim3 grid((w + 255) / 256, (h + 3) / 4, n_frames), block(64, 4);
+        hipLaunchKernelGGL(interpolate_r2_kernel, grid, block, 0, s, src, src_step, src_fs, dst, dst_step, dst_fs, w, h, min_disp16, max_disp);
+        return;
+    }
     dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
     hipLaunchKernelGGL(interpolate_kernel, grid, block, 0, s, src, src_step, src_fs, dst, dst_step, dst_fs, w, h,
                        radius, min_disp16, max_disp);
