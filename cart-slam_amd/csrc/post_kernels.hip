@@ -137,53 +137,62 @@ void launch_dir_derivative(const int16_t *disp, size_t step, size_t fs, int16_t 
 }
 
 // ------------------------------------------------------------------ plane derivative (5-tap vertical mean, 1-px diff)
-__device__ __forceinline__ int lowpass5(const int16_t *disp, size_t step, size_t fs, int frame, int x, int y, int h) {
-    if (y < 0 || y >= h) return INVALID;
-    int16_t sum = 0;  // derivative_t accumulator: wraps exactly like planeseg.cu:62
-    int count = 0;
-#pragma unroll
-    for (int k = -2; k <= 2; ++k) {
-        const int yy = y + k;
-        if (yy < 0 || yy >= h) continue;
-        const int16_t v = row_ptr(disp, fs, step, frame, yy)[x];
-        if (v != INVALID) { sum = (int16_t)(sum + v); ++count; }
-    }
-    return count == 0 ? INVALID : (int)(int16_t)((int)sum / count);
-}
+// A thread owns one column of PD_ROWS output rows: it loads the PD_ROWS + 6 disparities its outputs depend on once and slides
+// the 5-tap sums over them.  The low-pass accumulator of the reference is the 16-bit derivative_t (planeseg.cu:62): summing
+// in int and truncating once gives the same value because wrapping addition is associative.
+// The block histogram is kept in 16 copies, one per lane%16 and skewed by a bank each: disparity slopes cluster on two or
+// three values per wave, which on a single copy serialises the LDS atomics 64 deep.
+constexpr int PD_ROWS = 8, PD_COPIES = 16, PD_PITCH = 257;
 
 __global__ __launch_bounds__(256) void plane_derivative_kernel(const int16_t *disp, size_t step, size_t fs, int16_t *out,
                                                                size_t ostep, size_t ofs, int32_t *hist256, size_t hist_fs,
                                                                int w, int h) {
-    __shared__ int lh[256];
+    __shared__ int lh[PD_COPIES * PD_PITCH];
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    lh[tid] = 0;
+    for (int i = tid; i < PD_COPIES * PD_PITCH; i += 256) lh[i] = 0;
     __syncthreads();
     const int x = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.z;
-    const int ybase = blockIdx.y * 16 + threadIdx.y * 4;
+    const int ybase = blockIdx.y * (4 * PD_ROWS) + threadIdx.y * PD_ROWS;
     if (x < w && ybase < h) {
-        // sliding: lp(y-1), lp(y), lp(y+1) for the 4 rows of this thread
-        int lpm = lowpass5(disp, step, fs, frame, x, ybase - 1, h);
-        int lpc = lowpass5(disp, step, fs, frame, x, ybase, h);
-        for (int r = 0; r < 4; ++r) {
+        int v[PD_ROWS + 6];   // rows ybase-3 .. ybase+PD_ROWS+2; INVALID where outside the image
+#pragma unroll
+        for (int j = 0; j < PD_ROWS + 6; ++j) {
+            const int yy = ybase - 3 + j;
+            v[j] = (yy >= 0 && yy < h) ? (int)row_ptr(disp, fs, step, frame, yy)[x] : INVALID;
+        }
+        int lp[PD_ROWS + 2];  // low-pass of rows ybase-1 .. ybase+PD_ROWS
+#pragma unroll
+        for (int j = 0; j < PD_ROWS + 2; ++j) {
+            const int y = ybase - 1 + j;
+            int sum = 0, count = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (v[j + k] != INVALID) { sum += v[j + k]; ++count; }
+            lp[j] = (y < 0 || y >= h || count == 0) ? INVALID : (int)(int16_t)((int)(int16_t)sum / count);
+        }
+        int *mine = lh + (threadIdx.x & (PD_COPIES - 1)) * PD_PITCH;
+#pragma unroll
+        for (int r = 0; r < PD_ROWS; ++r) {
             const int y = ybase + r;
             if (y >= h) break;
-            const int lpp = lowpass5(disp, step, fs, frame, x, y + 1, h);
             int o = INVALID;
-            if (lpm != INVALID && lpc != INVALID && lpp != INVALID) {
-                o = (int16_t)(lpp - lpm);
-                if (o >= -128 && o <= 127) atomicAdd(&lh[o + 128], 1);
+            if (lp[r] != INVALID && lp[r + 1] != INVALID && lp[r + 2] != INVALID) {
+                o = (int16_t)(lp[r + 2] - lp[r]);
+                if (o >= -128 && o <= 127) atomicAdd(&mine[o + 128], 1);
             }
             row_ptr(out, ofs, ostep, frame, y)[x] = (int16_t)o;
-            lpm = lpc; lpc = lpp;
         }
     }
     __syncthreads();
-    if (lh[tid]) atomicAdd(&hist256[(size_t)frame * hist_fs + tid], lh[tid]);  // cumulative, planeseg.cu:157
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < PD_COPIES; ++c) total += lh[c * PD_PITCH + tid];
+    if (total) atomicAdd(&hist256[(size_t)frame * hist_fs + tid], total);  // cumulative, planeseg.cu:157
 }
 
 void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
                              int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 15) / 16, n_frames), block(64, 4);
+    dim3 grid((w + 63) / 64, (h + 4 * PD_ROWS - 1) / (4 * PD_ROWS), n_frames), block(64, 4);
     hipLaunchKernelGGL(plane_derivative_kernel, grid, block, 0, s, disp, step, fs, out, ostep, ofs, hist256, hist_fs, w, h);
 }
 
