@@ -98,6 +98,25 @@ class Engine:
                                                            _stream_ptr()), "cart_compute_disparity_batch")
         return out
 
+    def compute_disparity_multi(self, lefts, rights, outs=None):
+        """Frames in separate allocations (lists of [H,W] or [H,W,3] uint8 tensors with a common row step) in ONE launch
+        sequence: what a module adapter uses to coalesce concurrently entered frames."""
+        import torch
+        n = len(lefts)
+        if n == 0 or len(rights) != n:
+            raise EngineError("lefts/rights must be non-empty lists of the same length")
+        ch = 3 if lefts[0].dim() == 3 else 1
+        if outs is None:
+            outs = [torch.empty((self.height, self.width), dtype=torch.int16, device=lefts[0].device) for _ in range(n)]
+        geo = [[_geom(t, inner) for t in ts] for ts, inner in ((lefts, 2 if ch == 3 else 1), (rights, 2 if ch == 3 else 1), (outs, 1))]
+        for ts, g in zip((lefts, rights, outs), geo):
+            if any(tuple(t.shape[:2]) != (self.height, self.width) for t in ts) or len({x[2] for x in g}) != 1:
+                raise EngineError("every image of one kind must be HxW with the same row step")
+        tables = [(C.c_void_p * n)(*[x[1].value for x in g]) for g in geo]
+        self._check(self._lib.cart_compute_disparity_multi(self._h, n, tables[0], geo[0][0][2], tables[1], geo[1][0][2], ch,
+                                                           tables[2], geo[2][0][2], _stream_ptr()), "cart_compute_disparity_multi")
+        return outs
+
     def interpolate(self, disp, radius, iterations, min_disp16, max_disp):
         n, p, s, fs = _geom(disp, 1)
         self._check(self._lib.cart_interpolate(self._h, n, p, s, fs, radius, iterations, min_disp16, max_disp,

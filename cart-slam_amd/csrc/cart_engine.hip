@@ -77,7 +77,7 @@ struct cart_engine {
     std::condition_variable cv;
     std::vector<Slot> slots;
     unsigned long long release_counter = 0;    // guarded by mu
-    int chunk_frames = 16;          // frames per launch sequence inside one batched call
+    int chunk_frames = kLaunchFrames;          // frames per launch sequence inside one batched call
     bool post_only = false;         // no SGM workspaces (num_disparities == 0)
     bool timing = false;
     std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
@@ -373,18 +373,35 @@ int cart_engine_collect_timing(cart_engine *e, const char **names, float *mean_m
         }                                                                  \
     } while (0)
 
-int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
-                                 size_t left_frame_stride, const uint8_t *right, size_t right_step,
-                                 size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
-                                 size_t out_frame_stride, void *stream_) {
+namespace {
+// Where the frames of one call live: a base + stride per image (the batch entry point) or one pointer per frame (multi).
+struct FrameSet {
+    const uint8_t *left, *right; size_t left_fs, right_fs;
+    int16_t *out; size_t out_fs;
+    const uint8_t *const *lefts, *const *rights; int16_t *const *outs;   // non-NULL: scattered frames
+    size_t left_step, right_step, out_step;
+    ImageBatch images(bool right_side, int f0, int n) const {
+        const size_t step = right_side ? right_step : left_step;
+        if (!lefts) return strided_images((right_side ? right : left) + (size_t)f0 * (right_side ? right_fs : left_fs), step, right_side ? right_fs : left_fs);
+        ImageBatch b{}; b.step = step; b.scattered = 1;
+        for (int f = 0; f < n; ++f) b.frames[f] = (right_side ? rights : lefts)[f0 + f];
+        return b;
+    }
+    OutBatch output(int f0, int n) const {
+        if (!outs) return strided_out(reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(out) + (size_t)f0 * out_fs), out_step, out_fs);
+        OutBatch b{}; b.step = out_step; b.scattered = 1;
+        for (int f = 0; f < n; ++f) b.frames[f] = outs[f0 + f];
+        return b;
+    }
+};
+
+int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int channels, void *stream_) {
     if (!e) return fail("engine is NULL");
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
-    if (!left || !right || !out) return fail("NULL image pointer");
     if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
     const Geometry &g = e->g;
-    if (left_step < (size_t)g.w * channels || right_step < (size_t)g.w * channels) return fail("input step smaller than a row");
-    if (out_step < (size_t)g.w * 2 || (out_step & 1)) return fail("out_step must be even and >= 2*width");
-    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
+    if (fr.left_step < (size_t)g.w * channels || fr.right_step < (size_t)g.w * channels) return fail("input step smaller than a row");
+    if (fr.out_step < (size_t)g.w * 2 || (fr.out_step & 1)) return fail("out_step must be even and >= 2*width");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(e->params.device_id));
     if (std::min(n_frames, e->chunk_frames) >= e->fused_min_frames) {
@@ -412,14 +429,12 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
         uint16_t *wl = e->wta_l + s0 * g.npx;
         uint32_t *rpk = e->right_pk + s0 * g.npx;
         int16_t *ta = e->tmp_a + s0 * g.npx, *tb = e->tmp_b + s0 * g.npx;
-        int16_t *o = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(out) + (size_t)f0 * out_frame_stride);
+        const OutBatch o = fr.output(f0, n);
         hipStream_t stream = st;  // STAGE records on the stream the kernels are launched on
         TimingRec *rec_save = rec;
         if (!timed) rec = nullptr;
         STAGE("census");
-        ImageBatch lb{left + (size_t)f0 * left_frame_stride, left_step, left_frame_stride};
-        ImageBatch rb{right + (size_t)f0 * right_frame_stride, right_step, right_frame_stride};
-        launch_census(lb, rb, channels, n, gl, gr, cl, cr, rpk, g, st);
+        launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
         STAGE("aggregate");
         const bool fused = n >= e->fused_min_frames && e->rv_partial;
         AggArgs a = fused ? e->agg_fused : e->agg;
@@ -430,17 +445,16 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
         else launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
         STAGE("post");
         if (!smooth) {
-            launch_post(wl, rpk, gl, o, out_step, out_frame_stride, g, n, st);
+            launch_post(wl, rpk, gl, o, g, n, st);
         } else {
-            launch_post(wl, rpk, gl, ta, tight_step, tight_fs, g, n, st);
+            launch_post(wl, rpk, gl, strided_out(ta, tight_step, tight_fs), g, n, st);
             STAGE("interpolate");
             // disparity.hpp:27-28: minDisparity = cfg*16, maxDisparity = image width (not x16)
             const int min16 = e->params.min_disparity * 16, maxd = g.w;
             int16_t *src = ta, *dst = tb;
             for (int it = 0; it < iters; ++it) {
                 const bool last = it == iters - 1;
-                if (last) launch_interpolate(src, tight_step, tight_fs, o, out_step, out_frame_stride, g.w, g.h, radius, min16, maxd, n, st);
-                else launch_interpolate(src, tight_step, tight_fs, dst, tight_step, tight_fs, g.w, g.h, radius, min16, maxd, n, st);
+                launch_interpolate(src, tight_step, tight_fs, last ? o : strided_out(dst, tight_step, tight_fs), g.w, g.h, radius, min16, maxd, n, st);
                 std::swap(src, dst);
             }
         }
@@ -459,6 +473,33 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
     release(l);
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
     return 0;
+}
+}  // namespace
+
+int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
+                                 size_t left_frame_stride, const uint8_t *right, size_t right_step,
+                                 size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
+                                 size_t out_frame_stride, void *stream) {
+    if (!left || !right || !out) return fail("NULL image pointer");
+    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
+    FrameSet fr{};
+    fr.left = left; fr.right = right; fr.left_fs = left_frame_stride; fr.right_fs = right_frame_stride; fr.out = out; fr.out_fs = out_frame_stride;
+    fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
+    return compute_disparity_impl(e, n_frames, fr, channels, stream);
+}
+
+int cart_compute_disparity_multi(cart_engine *e, int n_frames, const uint8_t *const *left, size_t left_step,
+                                 const uint8_t *const *right, size_t right_step, int channels, int16_t *const *out,
+                                 size_t out_step, void *stream) {
+    if (!left || !right || !out) return fail("NULL pointer table");
+    for (int f = 0; f < n_frames; ++f) {
+        if (!left[f] || !right[f] || !out[f]) return fail("NULL image pointer in a pointer table");
+        if (reinterpret_cast<uintptr_t>(out[f]) & 1) return fail("output images must be 2-byte aligned");
+    }
+    FrameSet fr{};
+    fr.lefts = left; fr.rights = right; fr.outs = out;
+    fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
+    return compute_disparity_impl(e, n_frames, fr, channels, stream);
 }
 
 int cart_compute_disparity(cart_engine *e, const uint8_t *left, size_t left_step, const uint8_t *right,
@@ -481,10 +522,10 @@ int cart_interpolate(cart_engine *e, int n_frames, int16_t *disp, size_t step, s
     int16_t *ta = e->tmp_a + (size_t)l.s0 * g.npx, *tb = e->tmp_b + (size_t)l.s0 * g.npx;
     const size_t ts = (size_t)g.w * 2, tfs = g.npx * 2;
     // pass 0 reads the caller's buffer, the last pass writes it; an extra tight copy keeps Jacobi semantics
-    launch_interpolate(disp, step, frame_stride, ta, ts, tfs, g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
+    launch_interpolate(disp, step, frame_stride, strided_out(ta, ts, tfs), g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
     int16_t *src = ta, *dst = tb;
     for (int it = 1; it < iterations; ++it) {
-        launch_interpolate(src, ts, tfs, dst, ts, tfs, g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
+        launch_interpolate(src, ts, tfs, strided_out(dst, ts, tfs), g.w, g.h, radius, min_disp16, max_disp, n_frames, stream);
         std::swap(src, dst);
     }
     hipError_t err = hipSuccess;
@@ -943,7 +984,7 @@ int cart_optical_flow(cart_engine *e, const uint8_t *cur, size_t cur_step, const
     uint32_t *cen_c = reinterpret_cast<uint32_t *>(ws + ((2 * g.npx + 255) & ~(size_t)255));
     uint32_t *cen_p = cen_c + g.census_elems;
     uint32_t *scratch = cen_p + g.census_elems;   // census_kernel also resets a right-view plane: unused here
-    ImageBatch cb{cur, cur_step, 0}, pb{prev, prev_step, 0};
+    const ImageBatch cb = strided_images(cur, cur_step, 0), pb = strided_images(prev, prev_step, 0);
     launch_census(cb, pb, channels, 1, gray_c, gray_p, cen_c, cen_p, scratch, g, stream);
     launch_block_flow(cen_c, cen_p, g, radius, block, flow, flow_step, stream);
     hipError_t err = hipGetLastError();

@@ -47,10 +47,29 @@ struct AggArgs {
     DirDesc dirs[kMaxPaths];
 };
 
-struct ImageBatch {   // pitched caller image(s)
+constexpr int kLaunchFrames = 16;   // frames per launch sequence (cart_engine::chunk_frames) = size of the per-launch frame tables
+
+// Pitched caller image(s) of one launch: frame f starts at ptr + f * frame_stride, or -- for frames that live in separate
+// allocations (cart_compute_disparity_multi) -- at frames[f].
+struct ImageBatch {
     const uint8_t *ptr;
     size_t step, frame_stride;
+    const uint8_t *frames[kLaunchFrames];
+    int scattered;
 };
+inline ImageBatch strided_images(const uint8_t *ptr, size_t step, size_t frame_stride) {
+    ImageBatch b{}; b.ptr = ptr; b.step = step; b.frame_stride = frame_stride; return b;
+}
+
+struct OutBatch {   // the same for the s16 disparity images a launch writes
+    int16_t *ptr;
+    size_t step, frame_stride;
+    int16_t *frames[kLaunchFrames];
+    int scattered;
+};
+inline OutBatch strided_out(int16_t *ptr, size_t step, size_t frame_stride) {
+    OutBatch b{}; b.ptr = ptr; b.step = step; b.frame_stride = frame_stride; return b;
+}
 
 // ---- launchers (sgm_kernels.hip) ----
 void launch_census(const ImageBatch &left, const ImageBatch &right, int channels, int n_frames,
@@ -65,13 +84,11 @@ constexpr int kFusedUpPath = 1;
 size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s);
-void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, int16_t *out,
-                 size_t out_step, size_t out_frame_stride, const Geometry &g, int n_frames, hipStream_t s);
+void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames, hipStream_t s);
 
 // ---- launchers (post_kernels.hip) ----
-void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
-                        size_t dst_fs, int w, int h, int radius, int min_disp16, int max_disp, int n_frames,
-                        hipStream_t s);
+void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, const OutBatch &dst, int w, int h, int radius,
+                        int min_disp16, int max_disp, int n_frames, hipStream_t s);
 void launch_dir_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
                            int32_t *hist512, int w, int h, int n_frames, hipStream_t s);
 void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,

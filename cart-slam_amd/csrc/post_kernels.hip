@@ -25,9 +25,13 @@ __device__ __forceinline__ T *row_ptr(T *base, size_t frame_stride, size_t step,
     return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (size_t)frame * frame_stride + (size_t)y * step);
 }
 
+__device__ __forceinline__ int16_t *out_row(const OutBatch &o, int frame, int y) {
+    uint8_t *base = o.scattered ? reinterpret_cast<uint8_t *>(o.frames[frame]) : reinterpret_cast<uint8_t *>(o.ptr) + (size_t)frame * o.frame_stride;
+    return reinterpret_cast<int16_t *>(base + (size_t)y * o.step);
+}
+
 // ------------------------------------------------------------------ interpolate (one Jacobi pass)
-__global__ __launch_bounds__(256) void interpolate_kernel(const int16_t *src, size_t src_step, size_t src_fs,
-                                                          int16_t *dst, size_t dst_step, size_t dst_fs, int w, int h,
+__global__ __launch_bounds__(256) void interpolate_kernel(const int16_t *src, size_t src_step, size_t src_fs, OutBatch dst, int w, int h,
                                                           int radius, int min_disp16, int max_disp) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= w || y >= h) return;
@@ -44,14 +48,14 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const int16_t *src, si
         }
     }
     const unsigned min_count = (unsigned)(radius * radius + 1);  // interpolation.cu:33
-    row_ptr(dst, dst_fs, dst_step, frame, y)[x] = ((unsigned)count > min_count) ? (int16_t)(sum / count) : (int16_t)INVALID;
+    out_row(dst, frame, y)[x] = ((unsigned)count > min_count) ? (int16_t)(sum / count) : (int16_t)INVALID;
 }
 
 // radius 2 (3x3 window, the configured smoothing of the reference's KITTI setups): four adjacent pixels per thread share
 // their six window columns -- per column the sum and count of the valid values of the three rows, then three columns per
 // output.  sum / count (count <= 9, |sum| < 2^24) is a float division truncated, which is exact here.
-__global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
-                                                             size_t dst_fs, int w, int h, int min_disp16, int max_disp) {
+__global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src, size_t src_step, size_t src_fs, OutBatch dst, int w, int h,
+                                                             int min_disp16, int max_disp) {
     const int xb = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (xb >= w || y >= h) return;
     int csum[6], ccnt[6];
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src,
             if (v > min_disp16 && v < max_disp) { csum[c] += v; ++ccnt[c]; }
         }
     }
-    int16_t *orow = row_ptr(dst, dst_fs, dst_step, frame, y);
+    int16_t *orow = out_row(dst, frame, y);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (xb + i >= w) break;
@@ -80,17 +84,15 @@ __global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src,
     }
 }
 
-void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, int16_t *dst, size_t dst_step,
-                        size_t dst_fs, int w, int h, int radius, int min_disp16, int max_disp, int n_frames,
-                        hipStream_t s) {
+void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, const OutBatch &dst, int w, int h, int radius,
+                        int min_disp16, int max_disp, int n_frames, hipStream_t s) {
     if (radius == 2 && min_disp16 > -(1 << 20) && max_disp < (1 << 20)) {
         dim3 grid((w + 255) / 256, (h + 3) / 4, n_frames), block(64, 4);
-        hipLaunchKernelGGL(interpolate_r2_kernel, grid, block, 0, s, src, src_step, src_fs, dst, dst_step, dst_fs, w, h, min_disp16, max_disp);
+        hipLaunchKernelGGL(interpolate_r2_kernel, grid, block, 0, s, src, src_step, src_fs, dst, w, h, min_disp16, max_disp);
         return;
     }
     dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
-    hipLaunchKernelGGL(interpolate_kernel, grid, block, 0, s, src, src_step, src_fs, dst, dst_step, dst_fs, w, h,
-                       radius, min_disp16, max_disp);
+    hipLaunchKernelGGL(interpolate_kernel, grid, block, 0, s, src, src_step, src_fs, dst, w, h, radius, min_disp16, max_disp);
 }
 
 // ------------------------------------------------------------------ directional derivatives + 2x256 histogram

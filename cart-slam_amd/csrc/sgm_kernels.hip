@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
                                                      uint32_t *cen_r, uint32_t *right_pk, Geometry g) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[CT_LH * CT_PITCH];
     const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
-    const ImageBatch img = side ? right : left;
-    const uint8_t *src = img.ptr + (size_t)frame * img.frame_stride;
+    // the two sides are read in place: a by-value copy of the selected batch would put its frame table in scratch
+    const uint8_t *src;
+    size_t img_step;
+    if (side) { src = right.scattered ? right.frames[frame] : right.ptr + (size_t)frame * right.frame_stride; img_step = right.step; }
+    else { src = left.scattered ? left.frames[frame] : left.ptr + (size_t)frame * left.frame_stride; img_step = left.step; }
     uint8_t *gray = (side ? gray_r : gray_l) + (size_t)frame * g.npx;
     uint32_t *cen = (side ? cen_r : cen_l) + (size_t)frame * g.census_elems;
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
         const int gx = x0 - 4 + tx, gy = y0 - 3 + ty;
         uint32_t v = 0;
         if (gx >= 0 && gx < g.w && gy >= 0 && gy < g.h) {
-            const uint8_t *row = src + (size_t)gy * img.step;
+            const uint8_t *row = src + (size_t)gy * img_step;
             if (channels == 3) {
                 const uint32_t b = row[3 * gx], gg = row[3 * gx + 1], r = row[3 * gx + 2];
                 v = (1868u * b + 9617u * gg + 4899u * r + 8192u) >> 14;
@@ -1036,8 +1039,7 @@ __device__ __forceinline__ uint32_t median_at(const T *img, int x, int y, int w,
 }
 
 __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const uint32_t *right_pk,
-                                                   const uint8_t *gray_l, int16_t *out, size_t out_step,
-                                                   size_t out_frame_stride, Geometry g) {
+                                                   const uint8_t *gray_l, OutBatch out, Geometry g) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= g.w || y >= g.h) return;
     const uint16_t *wl = wta_l + (size_t)frame * g.npx;
@@ -1053,15 +1055,14 @@ __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const 
         }
     }
     const int v = invalid ? (g.min_disp - 1) * 16 : (int)ml + g.min_disp * 16;
-    int16_t *orow = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(out) + (size_t)frame * out_frame_stride +
-                                                (size_t)y * out_step);
-    orow[x] = (int16_t)v;
+    uint8_t *obase = out.scattered ? reinterpret_cast<uint8_t *>(out.frames[frame]) : reinterpret_cast<uint8_t *>(out.ptr) + (size_t)frame * out.frame_stride;
+    reinterpret_cast<int16_t *>(obase + (size_t)y * out.step)[x] = (int16_t)v;
 }
 
-void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, int16_t *out, size_t out_step,
-                 size_t out_frame_stride, const Geometry &g, int n_frames, hipStream_t s) {
+void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g,
+                 int n_frames, hipStream_t s) {
     dim3 grid((g.w + 63) / 64, (g.h + 3) / 4, n_frames), block(64, 4);
-    hipLaunchKernelGGL(post_kernel, grid, block, 0, s, wta_l, right_pk, gray_l, out, out_step, out_frame_stride, g);
+    hipLaunchKernelGGL(post_kernel, grid, block, 0, s, wta_l, right_pk, gray_l, out, g);
 }
 
 }  // namespace cart_amd

@@ -21,6 +21,11 @@
 #include "module.hpp"
 
 namespace cart {
+// Frames in flight: the reference's compile-time CARTSLAM_CONCURRENT_RUN_LIMIT (include/cartslam.hpp:4), overridable at run
+// time by the environment variable of the same name (cart_slam_amd --inflight N sets it).  Engines size their workspace
+// rings with it, so it has to be fixed before the modules are constructed.
+size_t concurrentRunLimit();
+
 
 class System;
 
@@ -38,7 +43,7 @@ class SystemRunData : public DataContainer {
 class System : public DataContainer {
    public:
     explicit System(std::shared_ptr<DataSource> dataSource, size_t runRetention = CARTSLAM_RUN_RETENTION,
-                    size_t concurrentRunLimit = CARTSLAM_CONCURRENT_RUN_LIMIT);
+                    size_t concurrentRunLimit = cart::concurrentRunLimit());
     ~System();
 
     // one frame: next data element, every module once (cartslam.cpp:228-334). The future resolves when all

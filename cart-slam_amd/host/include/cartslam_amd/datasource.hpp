@@ -61,6 +61,7 @@ namespace sources {
 class KITTIDataSource : public DataSource {
    public:
     KITTIDataSource(const std::string &basePath, int sequence);
+    ~KITTIDataSource() override;
     bool isNextReady() override { return !isFinished(); }
     bool isFinished() override;
     DataElementType getProvidedType() override { return DataElementType::STEREO; }
@@ -70,8 +71,11 @@ class KITTIDataSource : public DataSource {
     std::shared_ptr<DataElement> getNextInternal() override;
 
    private:
+    class ReadAhead;
     std::string dir;
     int currentFrame = 0;
+    int readAheadWorkers = 0;
+    std::unique_ptr<ReadAhead> readAhead;  // started by the first getNext
 };
 }  // namespace sources
 }  // namespace cart

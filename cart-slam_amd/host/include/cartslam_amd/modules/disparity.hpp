@@ -36,9 +36,11 @@ class ImageDisparityModule : public SyncWrapperSystemModule {
                          int smoothingRadius = -1, int smoothingIterations = 5, int paths = 4, int p1 = 10, int p2 = 120,
                          int uniquenessRatio = 12);
     system_data_t runInternal(System &system, SystemRunData &data) override;
+    double meanFramesPerLaunch() const;  // frames per launch sequence so far (1 when coalescing is off)
 
    private:
     std::shared_ptr<EngineHandle> engine;
+    std::shared_ptr<class DisparityCoalescer> coalescer;  // NULL when CARTSLAM_COALESCE=0: one launch sequence per frame
 };
 
 class ImageDisparityDerivativeModule : public SyncWrapperSystemModule {

@@ -1,3 +1,5 @@
+#include <cstdlib>
+#include <algorithm>
 #include "cartslam_amd/cartslam.hpp"
 
 #include <algorithm>
@@ -16,6 +18,12 @@ std::shared_ptr<SystemRunData> SystemRunData::getRelativeRun(const int8_t offset
     const int64_t target = (int64_t)id + offset;
     if (target <= 0) throw std::invalid_argument("Index out of range");
     return system->getRunById((uint32_t)target);
+}
+
+size_t concurrentRunLimit() {
+    const char *env = std::getenv("CARTSLAM_CONCURRENT_RUN_LIMIT");
+    const long n = env ? std::atol(env) : 0;
+    return n > 0 ? (size_t)std::min(n, 64L) : (size_t)CARTSLAM_CONCURRENT_RUN_LIMIT;
 }
 
 System::System(std::shared_ptr<DataSource> dataSource, size_t runRetention, size_t concurrentRunLimit)

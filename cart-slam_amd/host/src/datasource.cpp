@@ -1,7 +1,13 @@
 #include "cartslam_amd/datasource.hpp"
 
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "cartslam_amd/png.hpp"
 
@@ -93,6 +99,68 @@ bool readCalibLine(std::string line, KITTICameraCalibration &calibration) {
 }
 }  // namespace
 
+// Read-ahead: `workers` threads read and decode the next frames (a 1242x375 KITTI PNG costs milliseconds of inflate, the
+// reference's cv::imread pays it inside getNext, kitti.cpp:155-161) while the frame loop is busy with earlier ones;
+// getNextInternal then only uploads.  At most `depth` decoded frames wait in host memory.  Errors travel with the frame
+// they belong to and are thrown by the getNext call that asks for it, exactly where the synchronous reader throws them.
+class KITTIDataSource::ReadAhead {
+   public:
+    struct Frame { HostImage left, right; std::string error; };
+    ReadAhead(std::string dir, int workers, int depth) : dir(std::move(dir)), depth(depth) {
+        for (int i = 0; i < workers; ++i) threads.emplace_back([this] { work(); });
+    }
+    ~ReadAhead() {
+        { std::lock_guard<std::mutex> lock(mutex); stop = true; }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    Frame take(int frame) {
+        std::unique_lock<std::mutex> lock(mutex);
+        consumer = frame;   // frames before this one are never asked for again
+        cv.notify_all();
+        cv.wait(lock, [&] { return ready.count(frame) != 0 || frame > lastFrame; });
+        if (!ready.count(frame)) { Frame none; none.error = "Could not read frame " + std::to_string(frame); return none; }  // past the end of the sequence
+        Frame out = std::move(ready[frame]);
+        ready.erase(frame);
+        consumer = frame + 1;
+        cv.notify_all();
+        return out;
+    }
+
+   private:
+    void work() {
+        for (;;) {
+            int frame;
+            {
+                std::unique_lock<std::mutex> lock(mutex);
+                cv.wait(lock, [&] { return stop || (claim < consumer + depth && claim <= lastFrame); });
+                if (stop) return;
+                frame = claim++;
+            }
+            Frame f;
+            bool exists = true;
+            try {
+                exists = readFrame(dir, 2, frame, f.left);
+                if (exists && !readFrame(dir, 3, frame, f.right)) f.error = "Could not read frame " + std::to_string(frame);
+            } catch (const std::exception &e) { f.error = e.what(); }
+            std::lock_guard<std::mutex> lock(mutex);
+            if (!exists) { f.error = "Could not read frame " + std::to_string(frame); lastFrame = std::min(lastFrame, frame); }  // end of the sequence: stop claiming
+            ready[frame] = std::move(f);
+            cv.notify_all();
+        }
+    }
+    const std::string dir;
+    const int depth;
+    std::mutex mutex;
+    std::condition_variable cv;
+    std::map<int, Frame> ready;
+    int claim = 0, consumer = 0, lastFrame = 1 << 30;
+    bool stop = false;
+    std::vector<std::thread> threads;
+};
+
+KITTIDataSource::~KITTIDataSource() = default;
+
 KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence) : DataSource(Size{}) {
     char seq[16];
     std::snprintf(seq, sizeof(seq), "%02d", sequence);
@@ -120,6 +188,9 @@ KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence) : Da
     } else if (std::ifstream(framePath(dir, 2, 0, "png")).is_open()) {
         throw std::runtime_error("Failed to open calibration file at " + calibPath + ": " + std::strerror(errno));  // kitti.cpp:100-103
     }
+    // CARTSLAM_READAHEAD = decoder threads (default 4, 0 = read inside getNext like the reference)
+    const char *env = std::getenv("CARTSLAM_READAHEAD");
+    readAheadWorkers = env ? std::max(0, std::min(16, std::atoi(env))) : 4;
     HostImage first;
     if (!readFrame(dir, 2, 0, first)) throw std::runtime_error("Could not read first frame under " + dir);
     imageSize.width = first.w; imageSize.height = first.h;
@@ -129,7 +200,14 @@ bool KITTIDataSource::isFinished() { return !frameExists(dir, 2, currentFrame); 
 
 std::shared_ptr<DataElement> KITTIDataSource::getNextInternal() {
     HostImage l, r;
-    if (!readFrame(dir, 2, currentFrame, l) || !readFrame(dir, 3, currentFrame, r)) throw std::runtime_error("Could not read frame " + std::to_string(currentFrame));
+    if (readAheadWorkers > 0) {
+        if (!readAhead) readAhead = std::make_unique<ReadAhead>(dir, readAheadWorkers, 2 * readAheadWorkers);
+        ReadAhead::Frame f = readAhead->take(currentFrame);
+        if (!f.error.empty()) throw std::runtime_error(f.error);
+        l = std::move(f.left); r = std::move(f.right);
+    } else if (!readFrame(dir, 2, currentFrame, l) || !readFrame(dir, 3, currentFrame, r)) {
+        throw std::runtime_error("Could not read frame " + std::to_string(currentFrame));
+    }
     ++currentFrame;
     const int type = l.channels == 3 ? CV_8UC3 : CV_8UC1;
     image_t dl(l.h, l.w, type), dr(r.h, r.w, type);

@@ -1,9 +1,11 @@
-// cart_slam_amd <source.json> <modules.json> [--frames N] [--dump DIR] [--sequential 1] [--timing FILE.csv]
+// cart_slam_amd <source.json> <modules.json> [--frames N] [--dump DIR] [--sequential 1] [--inflight N] [--timing FILE.csv]
 // (--sequential 1 finishes every frame before the next starts: the cumulative plane histogram then sees the frames in id
 //  order, which the reference's concurrent frame loop does not guarantee)
 // Frame loop of the reference's src/main.cpp:8-63 without logging/UI; --dump writes every frame's blackboard images as
 // raw little-endian files (<DIR>/<id>_<key>.bin) so that tests can compare them with the oracle.
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -25,11 +27,13 @@ int main(int argc, char **argv) {
         if (!std::strcmp(argv[i], "--frames")) maxFrames = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--dump")) dump = argv[i + 1];
         else if (!std::strcmp(argv[i], "--sequential")) sequential = std::atoi(argv[i + 1]) != 0;
+        else if (!std::strcmp(argv[i], "--inflight")) setenv("CARTSLAM_CONCURRENT_RUN_LIMIT", argv[i + 1], 1);  // frames in flight (reference: 12)
         else if (!std::strcmp(argv[i], "--timing")) cart::timing::Sink::instance().open(argv[i + 1]);
     }
     try {
         auto dataSource = cart::config::readDataSourceConfig(argv[1]);
-        auto system = std::make_shared<cart::System>(dataSource);
+        const size_t inflight = cart::concurrentRunLimit();
+        auto system = std::make_shared<cart::System>(dataSource, std::max<size_t>(CARTSLAM_RUN_RETENTION, inflight + 8), inflight);
         cart::config::readModuleConfig(argv[2], system);
         std::vector<std::future<void>> pending;
         int frames = 0;
@@ -70,7 +74,10 @@ int main(int argc, char **argv) {
             const cart::CameraIntrinsics K = dataSource->getCameraIntrinsics();
             q.write(reinterpret_cast<const char *>(K.Q), sizeof(K.Q));
         }
-        std::cout << "frames " << frames << " failed " << failed << "\n";
+        std::cout << "frames " << frames << " failed " << failed;
+        for (const auto &m : system->getModules())
+            if (auto d = std::dynamic_pointer_cast<cart::ImageDisparityModule>(m)) std::cout << " frames_per_launch " << d->meanFramesPerLaunch();
+        std::cout << "\n";
         return failed ? 2 : 0;
     } catch (const std::exception &e) {
         std::cerr << "fatal: " << e.what() << "\n";

@@ -2,7 +2,10 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -51,7 +54,7 @@ cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int
     p.width = res.width; p.height = res.height;
     p.min_disparity = minDisparity; p.num_disparities = numDisparities; p.paths = paths; p.p1 = p1; p.p2 = p2;
     p.uniqueness_ratio = uniq; p.smoothing_radius = radius; p.smoothing_iterations = iterations;
-    p.max_inflight = CARTSLAM_CONCURRENT_RUN_LIMIT;
+    p.max_inflight = (int)concurrentRunLimit();
     return p;
 }
 }  // namespace
@@ -63,12 +66,86 @@ EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }
 void EngineHandle::fail(const char *what) const { throw std::runtime_error(std::string(what) + ": " + cart_last_error(engine)); }
 
 // ---------------------------------------------------------------- disparity (disparity.cu:49-80)
+// The reference's runtime enters runInternal from up to CARTSLAM_CONCURRENT_RUN_LIMIT worker threads at once, one frame
+// each (cartslam.cpp:196).  One frame per launch sequence leaves path aggregation latency-bound on this GPU (0.67 ms per
+// frame against 0.10 ms per frame in a 16-frame launch), so the frames that are waiting at the same moment are handed to
+// the engine as ONE cart_compute_disparity_multi call.  Leader/follower, no extra thread and no timer: a caller whose
+// request is still queued becomes the leader as soon as fewer than `maxOutstanding` groups are on the GPU, takes every
+// compatible queued request, runs the group on its own stream and wakes the others.  A lone frame is dispatched at once
+// (no added latency at low load); groups only form while the GPU is already busy with earlier ones.
+class DisparityCoalescer {
+   public:
+    struct Request {
+        const uint8_t *left, *right; size_t leftStep, rightStep; int channels;
+        int16_t *out; size_t outStep;
+        bool queued = true, done = false;
+        std::string error;
+    };
+    DisparityCoalescer(std::shared_ptr<EngineHandle> engine, int maxGroup, int maxOutstanding)
+        : engine(std::move(engine)), maxGroup(maxGroup), maxOutstanding(maxOutstanding) {}
+
+    void run(Request &rq) {
+        std::unique_lock<std::mutex> lock(mutex);
+        pending.push_back(&rq);
+        while (!rq.done) {
+            if (!rq.queued || outstanding >= maxOutstanding) { cv.wait(lock); continue; }
+            // leader: this request + every queued one with the same image layout, oldest first
+            std::vector<Request *> group{&rq}, rest;
+            for (Request *q : pending) {
+                if (q == &rq) continue;
+                const bool fits = (int)group.size() < maxGroup && q->channels == rq.channels && q->leftStep == rq.leftStep &&
+                                  q->rightStep == rq.rightStep && q->outStep == rq.outStep;
+                (fits ? group : rest).push_back(q);
+            }
+            pending.swap(rest);
+            for (Request *q : group) q->queued = false;
+            ++outstanding;
+            lock.unlock();
+            std::string error;
+            try {
+                std::vector<const uint8_t *> lefts, rights;
+                std::vector<int16_t *> outs;
+                for (Request *q : group) { lefts.push_back(q->left); rights.push_back(q->right); outs.push_back(q->out); }
+                ScopedStream stream;
+                if (cart_compute_disparity_multi(engine->get(), (int)group.size(), lefts.data(), rq.leftStep, rights.data(), rq.rightStep, rq.channels,
+                                                 outs.data(), rq.outStep, stream.s) != 0)
+                    error = std::string("cart_compute_disparity_multi: ") + cart_last_error(engine->get());
+                else stream.wait();  // stream.waitForCompletion(), disparity.cu:77
+            } catch (const std::exception &e) { error = e.what(); }
+            lock.lock();
+            --outstanding;
+            ++groups; frames += group.size();
+            for (Request *q : group) { q->error = error; q->done = true; }
+            cv.notify_all();
+        }
+        if (!rq.error.empty()) throw std::runtime_error(rq.error);
+    }
+    // mean frames per launch sequence so far (diagnostics: the timing CSV / tests)
+    double meanGroup() { std::lock_guard<std::mutex> lock(mutex); return groups ? (double)frames / groups : 0.0; }
+
+   private:
+    std::shared_ptr<EngineHandle> engine;
+    const int maxGroup, maxOutstanding;
+    std::mutex mutex;
+    std::condition_variable cv;
+    std::vector<Request *> pending;
+    int outstanding = 0;
+    size_t groups = 0, frames = 0;
+};
+
 ImageDisparityModule::ImageDisparityModule(const Size imageRes, int minDisparity, int numDisparities, int /*blockSize: ignored by the CUDA SGM too*/,
                                            int smoothingRadius, int smoothingIterations, int paths, int p1, int p2, int uniquenessRatio)
     : SyncWrapperSystemModule("ImageDisparity") {
     this->providesData.push_back(CARTSLAM_KEY_DISPARITY);
-    engine = std::make_shared<EngineHandle>(imageRes, paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio));
+    cart_engine_params params = paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio);
+    // CARTSLAM_COALESCE = number of frame groups allowed on the GPU at once (default 2); 0 = one launch sequence per frame
+    const char *env = std::getenv("CARTSLAM_COALESCE");
+    const int outstanding = env ? std::atoi(env) : 2;
+    engine = std::make_shared<EngineHandle>(imageRes, params);
+    if (outstanding > 0) coalescer = std::make_shared<DisparityCoalescer>(engine, std::min(params.max_inflight, 16), outstanding);  // 16 = frames per launch sequence
 }
+
+double ImageDisparityModule::meanFramesPerLaunch() const { return coalescer ? coalescer->meanGroup() : 1.0; }
 
 system_data_t ImageDisparityModule::runInternal(System &, SystemRunData &data) {
     if (data.dataElement->type != DataElementType::STEREO) throw std::runtime_error("ImageDisparityModule requires StereoDataElement");
@@ -76,8 +153,13 @@ system_data_t ImageDisparityModule::runInternal(System &, SystemRunData &data) {
     const image_t &l = stereo->left, &r = stereo->right;
     const int channels = l.type() == CV_8UC3 ? 3 : 1;
     if ((l.type() != CV_8UC3 && l.type() != CV_8UC1) || r.type() != l.type()) throw std::runtime_error("ImageDisparityModule requires CV_8UC1 or CV_8UC3 images");
-    ScopedStream stream;
     auto disparity = std::make_shared<image_t>(l.rows, l.cols, CV_16SC1);
+    if (coalescer) {
+        DisparityCoalescer::Request rq{l.ptr<uint8_t>(), r.ptr<uint8_t>(), l.step, r.step, channels, disparity->ptr<int16_t>(), disparity->step};
+        coalescer->run(rq);
+        return MODULE_RETURN(CARTSLAM_KEY_DISPARITY, disparity);
+    }
+    ScopedStream stream;
     if (cart_compute_disparity(engine->get(), l.ptr<uint8_t>(), l.step, r.ptr<uint8_t>(), r.step, channels, disparity->ptr<int16_t>(), disparity->step, stream.s) != 0)
         engine->fail("cart_compute_disparity");
     stream.wait();  // stream.waitForCompletion(), disparity.cu:77

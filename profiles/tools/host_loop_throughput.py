@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [os.path.join(ROOT, "cart-slam_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 from cartslam import synth
-tmp = tempfile.mkdtemp(dir="/tmp")
+tmp = os.environ.get("PREPARE_ONLY") or tempfile.mkdtemp(dir="/tmp")  # PREPARE_ONLY=<dir>: write the data set + the four module lists there and stop
+os.makedirs(tmp, exist_ok=True)
 d = os.path.join(tmp, "ds", "sequences", "00"); os.makedirs(d + "/image_2"); os.makedirs(d + "/image_3")
 n = 240
 base = [synth.make_pair(1242, 375, 128, 4, frame=f) for f in range(4)]
@@ -18,16 +19,26 @@ for f in range(n):
         with open(f"{d}/image_{cam}/{f:06d}.pgm", "wb") as fh:
             fh.write(b"P5\n1242 375\n255\n"); fh.write(img.tobytes())
 json.dump({"type": "kitti", "path": os.path.join(tmp, "ds"), "sequence": 0}, open(tmp + "/src.json", "w"))
-for name, mods in (("disparity D=128 P=8 + planeseg", [{"type": "disparity", "num_disparities": 128, "paths": 8, "smoothing_radius": 2, "smoothing_iterations": 1},
-                                                        {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
-                   ("reference default (D=256, 4 paths) + planeseg", [{"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1},
-                                                                      {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}]),
-                   ("kitti-planeseg.json minus optflow (superpixels 24/8 sweeps, D=256 4 paths, derivative, depth, superpixel planeseg)", SP),
-                   ("kitti-planeseg.json complete (+ optflow stand-in R=8, temporal smoothing)", SP[:1] + [{"type": "optflow"}] + SP[1:-1] + [dict(SP[-1], use_temporal_smoothing=True)])):
+D128 = {"type": "disparity", "num_disparities": 128, "paths": 8, "smoothing_radius": 2, "smoothing_iterations": 1}
+DREF = {"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1}
+PEAK = {"type": "disparity_planeseg", "parameter_provider": {"type": "histogram_peak"}}
+CONFIGS = [("disparity D=128 P=8 + planeseg", [D128, PEAK]),
+           ("reference default (D=256, 4 paths) + planeseg", [DREF, PEAK]),
+           ("kitti-planeseg.json minus optflow (superpixels 24/8 sweeps, D=256 4 paths, derivative, depth, superpixel planeseg)", SP),
+           ("kitti-planeseg.json complete (+ optflow stand-in R=8, temporal smoothing)", SP[:1] + [{"type": "optflow"}] + SP[1:-1] + [dict(SP[-1], use_temporal_smoothing=True)]),
+           ("disparity D=128 P=8 alone", [D128])]   # index 4: only with ONLY=4
+ci = -1
+for name, mods in CONFIGS:
+    ci += 1
+    if str(ci) not in os.environ.get("ONLY", "0,1,2,3").split(","):   # ONLY=0,1: run these module lists only
+        continue
     json.dump(mods, open(tmp + "/mod.json", "w"))
+    if os.environ.get("PREPARE_ONLY"):
+        json.dump(mods, open(tmp + "/mod_%d.json" % sum(os.path.exists(tmp + "/mod_%d.json" % i) for i in range(8)), "w"))
+        continue
     exe = os.path.join(ROOT, "cart-slam_amd", "build", "cart_slam_amd")
     t0 = time.time()
-    r = subprocess.run([exe, tmp + "/src.json", tmp + "/mod.json", "--timing", tmp + "/t.csv"], capture_output=True, text=True)
+    r = subprocess.run([exe, tmp + "/src.json", tmp + "/mod.json", "--timing", tmp + "/t.csv"] + os.environ.get("EXTRA", "").split(), capture_output=True, text=True)   # EXTRA="--inflight 24"
     wall = time.time() - t0
     rows = [ln.strip().split(";") for ln in open(tmp + "/t.csv")][1:]
     fr = [x for x in rows if x[0] == "Frame"]

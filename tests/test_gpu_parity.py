@@ -679,3 +679,30 @@ def test_ccl_component_table(torch_cuda):
     et, en = O.ccl_stats(maps[0], O.ccl(maps[0])[0], max_components=5)
     assert int(n3[0]) == en and (table_s[0].cpu().numpy() == et).all()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,n", [(1, 5), (3, 19)])
+def test_multi_equals_batch(channels, n):
+    """cart_compute_disparity_multi (frames in separate allocations, here with a padded row step and shuffled order in
+    memory) gives the batch entry point's result bit for bit; 19 frames cross the 16-frame launch sequence."""
+    import torch
+    from cartslam import Engine, EngineError
+    w, h, D = 320, 96, 64
+    eng = Engine(w, h, num_disparities=D, paths=8, smoothing_radius=2, smoothing_iterations=1, max_inflight=n)
+    ls, rs = synth.make_batch(n, w, h, D, 4)
+    if channels == 3:
+        ls = np.stack([ls, ls // 2 + 3, 255 - ls], -1); rs = np.stack([rs, rs // 2 + 3, 255 - rs], -1)
+    L, R = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+    want = eng.compute_disparity(L, R).cpu().numpy()
+    pad = (0, 0, 0, 24) if channels == 3 else (0, 24)   # widen the row step
+    order = np.random.default_rng(5).permutation(n)
+    store = {int(f): (torch.nn.functional.pad(L[f], pad), torch.nn.functional.pad(R[f], pad), torch.full((h, w + 8), -7, dtype=torch.int16, device="cuda")) for f in order}
+    lefts = [store[f][0][:, :w] for f in range(n)]; rights = [store[f][1][:, :w] for f in range(n)]; outs = [store[f][2][:, :w] for f in range(n)]
+    eng.compute_disparity_multi(lefts, rights, outs)
+    torch.cuda.synchronize()
+    for f in range(n):
+        assert np.array_equal(outs[f].cpu().numpy(), want[f]), f
+        assert (store[f][2][:, w:] == -7).all()   # nothing written past the row
+    with pytest.raises(EngineError):
+        eng.compute_disparity_multi(lefts, rights[:-1])

@@ -46,10 +46,10 @@ def make_dataset(tmp, n, w, h, channels=1, seq=0):
     return src, frames
 
 
-def run_exe(src, modules, tmp, extra=()):
+def run_exe(src, modules, tmp, extra=(), env=None):
     mod = os.path.join(tmp, "modules.json")
     json.dump(modules, open(mod, "w"))
-    return subprocess.run([EXE, src, mod, *extra], capture_output=True, text=True, timeout=600)
+    return subprocess.run([EXE, src, mod, *extra], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
 
 
 def test_exe_exists():
@@ -132,16 +132,21 @@ def test_frame_loop_matches_oracle(tmp_path, channels):
 
 
 @pytest.mark.gpu
-def test_concurrent_frames_disparity(tmp_path):
+@pytest.mark.parametrize("coalesce", ["2", "1", "0"])
+def test_concurrent_frames_disparity(tmp_path, coalesce):
     """Up to 12 frames in flight through one module object (include/cartslam.hpp:4-5): disparity is frame-local, so
-    every frame must still be bit-exact whatever the interleaving."""
+    every frame must still be bit-exact whatever the interleaving -- whether the module hands the frames that wait
+    together to the engine as one launch sequence (CARTSLAM_COALESCE = groups on the GPU at once) or one by one (0)."""
     tmp = str(tmp_path)
-    w, h, n = 320, 96, 14
+    w, h, n = 320, 96, 30
     src, frames = make_dataset(tmp, n, w, h)
     os.makedirs(os.path.join(tmp, "dump"))
     tcsv = os.path.join(tmp, "timing.csv")
-    r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "paths": 8}], tmp, ("--dump", os.path.join(tmp, "dump"), "--timing", tcsv))
+    r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "paths": 8}], tmp, ("--dump", os.path.join(tmp, "dump"), "--timing", tcsv),
+                env={"CARTSLAM_COALESCE": coalesce})
     assert r.returncode == 0, r.stderr
+    per_launch = float(r.stdout.split("frames_per_launch")[1].split()[0])
+    assert per_launch == 1.0 if coalesce == "0" else 1.0 <= per_launch <= 12.0, r.stdout
     rows = [ln.strip().split(";") for ln in open(tcsv)]
     assert rows[0][:6] == ["name", "run_id", "time_init", "time_start", "time_end", "duration_ms"]  # include/timing.hpp:59
     assert sorted(int(x[1]) for x in rows[1:] if x[0] == "ImageDisparity") == list(range(1, n + 1))
@@ -195,12 +200,13 @@ def test_kitti_calibration_errors(tmp_path):
 def test_kitti_png_source_and_depth(tmp_path, color):
     """image_2/image_3 PNGs + calib.txt -> Q (src/sources/kitti.cpp:89-149) -> disparity -> depth (src/modules/depth.cpp)."""
     tmp = str(tmp_path)
-    w, h, n = 300, 100, 2
+    w, h, n = 300, 100, 11 if color else 2   # 11 frames: more than the read-ahead depth
     src, frames = make_kitti_png_dataset(tmp, n, w, h, color)
     os.makedirs(os.path.join(tmp, "dump"))
     modules = [{"type": "disparity", "num_disparities": 128, "smoothing_radius": 2, "smoothing_iterations": 1}, {"type": "depth"},
                {"type": "depth_visualization"}]
-    r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump")))
+    # colour files through the read-ahead decoder pool (default), gray files read inside getNext like the reference
+    r = run_exe(src, modules, tmp, ("--dump", os.path.join(tmp, "dump")), env={"CARTSLAM_READAHEAD": "4" if color else "0"})
     assert r.returncode == 0, r.stderr
     Q = np.fromfile(os.path.join(tmp, "dump", "Q.bin"), np.float32).reshape(4, 4)
     assert np.array_equal(Q, O.kitti_q_matrix(P_ROWS[2], P_ROWS[3])), Q
