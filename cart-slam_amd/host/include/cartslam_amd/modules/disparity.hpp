@@ -39,6 +39,7 @@ class ImageDisparityModule : public SyncWrapperSystemModule {
     double meanFramesPerLaunch() const;  // frames per launch sequence so far (1 when coalescing is off)
 
    private:
+    const Size imageRes;
     std::shared_ptr<EngineHandle> engine;
     std::shared_ptr<class DisparityCoalescer> coalescer;  // NULL when CARTSLAM_COALESCE=0: one launch sequence per frame
 };

@@ -135,7 +135,7 @@ class DisparityCoalescer {
 
 ImageDisparityModule::ImageDisparityModule(const Size imageRes, int minDisparity, int numDisparities, int /*blockSize: ignored by the CUDA SGM too*/,
                                            int smoothingRadius, int smoothingIterations, int paths, int p1, int p2, int uniquenessRatio)
-    : SyncWrapperSystemModule("ImageDisparity") {
+    : SyncWrapperSystemModule("ImageDisparity"), imageRes(imageRes) {
     this->providesData.push_back(CARTSLAM_KEY_DISPARITY);
     cart_engine_params params = paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio);
     // CARTSLAM_COALESCE = number of frame groups allowed on the GPU at once (default 2); 0 = one launch sequence per frame
@@ -153,6 +153,10 @@ system_data_t ImageDisparityModule::runInternal(System &, SystemRunData &data) {
     const image_t &l = stereo->left, &r = stereo->right;
     const int channels = l.type() == CV_8UC3 ? 3 : 1;
     if ((l.type() != CV_8UC3 && l.type() != CV_8UC1) || r.type() != l.type()) throw std::runtime_error("ImageDisparityModule requires CV_8UC1 or CV_8UC3 images");
+    // the engine's workspaces are sized for the resolution given to the constructor (disparity.hpp:26): anything else would run past them
+    if (l.cols != imageRes.width || l.rows != imageRes.height || r.cols != l.cols || r.rows != l.rows)
+        throw std::runtime_error("ImageDisparityModule: image size " + std::to_string(l.cols) + "x" + std::to_string(l.rows) + " does not match the module's " +
+                                 std::to_string(imageRes.width) + "x" + std::to_string(imageRes.height));
     auto disparity = std::make_shared<image_t>(l.rows, l.cols, CV_16SC1);
     if (coalescer) {
         DisparityCoalescer::Request rq{l.ptr<uint8_t>(), r.ptr<uint8_t>(), l.step, r.step, channels, disparity->ptr<int16_t>(), disparity->step};

@@ -138,8 +138,12 @@ def test_concurrent_frames_disparity(tmp_path, coalesce):
     every frame must still be bit-exact whatever the interleaving -- whether the module hands the frames that wait
     together to the engine as one launch sequence (CARTSLAM_COALESCE = groups on the GPU at once) or one by one (0)."""
     tmp = str(tmp_path)
-    w, h, n = 320, 96, 30
-    src, frames = make_dataset(tmp, n, w, h)
+    w, h, n, distinct = 320, 96, 30, 5
+    src, frames = make_dataset(tmp, distinct, w, h)
+    seq_dir = os.path.join(tmp, "dataset", "sequences", "00")
+    for f in range(distinct, n):   # frames 5..29 repeat the first five: the oracle runs once per distinct frame
+        for cam in ("image_2", "image_3"):
+            os.link(os.path.join(seq_dir, cam, "%06d.pgm" % (f % distinct)), os.path.join(seq_dir, cam, "%06d.pgm" % f))
     os.makedirs(os.path.join(tmp, "dump"))
     tcsv = os.path.join(tmp, "timing.csv")
     r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "paths": 8}], tmp, ("--dump", os.path.join(tmp, "dump"), "--timing", tcsv),
@@ -151,8 +155,9 @@ def test_concurrent_frames_disparity(tmp_path, coalesce):
     assert rows[0][:6] == ["name", "run_id", "time_init", "time_start", "time_end", "duration_ms"]  # include/timing.hpp:59
     assert sorted(int(x[1]) for x in rows[1:] if x[0] == "ImageDisparity") == list(range(1, n + 1))
     assert sum(1 for x in rows[1:] if x[0] == "Frame") == n
-    for f, (l, rr) in enumerate(frames):
-        assert (load(tmp, f + 1, "disparity", np.int16, (h, w)) == O.disparity_module(l, rr, 64, 8, 4)).all(), f"frame {f + 1}"
+    want = [O.disparity_module(l, rr, 64, 8, 4) for l, rr in frames]
+    for f in range(n):
+        assert (load(tmp, f + 1, "disparity", np.int16, (h, w)) == want[f % distinct]).all(), f"frame {f + 1}"
 
 
 # ---------------------------------------------------------------- KITTI source (PNG + calib.txt) and depth module
