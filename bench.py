@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
+    ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
+                    "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
@@ -195,6 +197,30 @@ def main():
         torch.cuda.synchronize()
         pcie = {"pairs_per_s": round(B * n_pcie / (time.perf_counter() - tp), 1), "steps": n_pcie,
                 "moved_per_pair": "2 x gray H2D (pinned), s16 disparity + u8 planes D2H"}
+    seq = None
+    if args.sequence:
+        # Informational (never `value`): BASELINE configs[4].  64 frames when they divide over the ranks and fit a batch.
+        n_seq = 64 if (64 % world == 0 and 64 // world <= B) else world * B
+        sl = sr = None
+        if rank == 0:
+            k = (n_seq + n_distinct - 1) // n_distinct
+            sl = torch.from_numpy(np.concatenate([ls] * k)[:n_seq]).cuda()
+            sr = torch.from_numpy(np.concatenate([rs] * k)[:n_seq]).cuda()
+        for _ in range(2):
+            pipe.process_sequence(sl, sr, n_seq)
+        torch.cuda.synchronize(); barrier()
+        ts = time.perf_counter()
+        n_rounds = 5
+        for _ in range(n_rounds):
+            got = pipe.process_sequence(sl, sr, n_seq)
+        torch.cuda.synchronize(); barrier()
+        tseq = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tseq, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            assert tuple(got["disparity"].shape) == (n_seq, h, w) and tuple(got["planes"].shape) == (n_seq, h, w)
+            seq = {"frames": n_seq, "pairs_per_s": round(n_seq * n_rounds / float(tseq.item()), 1), "rounds": n_rounds,
+                   "moved": "scatter of 2 gray images per frame from rank 0, gather of s16 disparity + u8 planes to rank 0"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -241,6 +267,8 @@ def main():
         }
         if pcie:
             out["pcie_inclusive"] = pcie
+        if seq:
+            out["sequence_mode"] = seq
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, h, D, P)
         print(json.dumps(out), flush=True)

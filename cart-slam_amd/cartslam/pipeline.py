@@ -55,6 +55,47 @@ def shard_ids(first_id, n_local, rank, world):
     return [first_id + k * world + rank for k in range(n_local)]
 
 
+def scatter_sequence(frames, n_total, like, root=0, group=None):
+    """Batched-sequence mode (BASELINE.json configs[4]: a 64-frame sequence that starts on one rank): frame k of the
+    sequence goes to rank k mod world, the interleaving of shard_ids.  `frames` is the [n_total, ...] tensor on `root`
+    (ignored elsewhere); `like` = (per-frame shape, dtype, device) so that the other ranks can post their receive.
+    Returns this rank's [n_total / world, ...] tensor.  One scatter (RCCL: grouped point-to-point over xGMI, rank 0 has
+    a direct link to every peer) -- not a ring collective."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if n_total % world:
+        raise ValueError(f"sequence length {n_total} is not a multiple of the world size {world}")
+    shape, dtype, device = like
+    on_host = dist.get_backend(group) == "gloo"   # RCCL moves device tensors; gloo (CPU rehearsals) moves host copies
+    mine = torch.empty((n_total // world,) + tuple(shape), dtype=dtype, device="cpu" if on_host else device)
+    parts = None
+    if rank == root:
+        if tuple(frames.shape) != (n_total,) + tuple(shape) or frames.dtype != dtype:
+            raise ValueError(f"root holds {tuple(frames.shape)} {frames.dtype}, expected {(n_total,) + tuple(shape)} {dtype}")
+        parts = [(frames[r::world].cpu() if on_host else frames[r::world]).contiguous() for r in range(world)]
+    dist.scatter(mine, parts, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
+    return mine.to(device)
+
+
+def gather_sequence(local, root=0, group=None):
+    """Inverse of scatter_sequence: on `root` the frames of all ranks back in sequence order ([n_total, ...]), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    device = local.device
+    local = (local.cpu() if dist.get_backend(group) == "gloo" else local).contiguous()
+    wire = local.view(torch.uint8)   # images travel as bytes: neither RCCL nor gloo has a 16-bit integer type
+    parts = [torch.empty_like(wire) for _ in range(world)] if rank == root else None
+    dist.gather(wire, parts, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+    if rank != root:
+        return None
+    full = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
+    for r in range(world):
+        full[r::world] = parts[r].view(local.dtype).to(device)
+    return full
+
+
 class StereoPipeline:
     """device_schedule=True (default) replays the plane-parameter bookkeeping on the GPU
     (cart_plane_schedule_advance), so a step has no device->host round trip; False uses the host restatement
@@ -96,6 +137,25 @@ class StereoPipeline:
             out = self._process_batch(left, right, disp)
             out["done"] = self.side.record_event()
         return out
+
+    def process_sequence(self, left, right, n_total, root=0, channels=1, keys=("disparity", "planes")):
+        """A sequence that lives on `root` ([n_total, H, W] gray or, with channels=3, [n_total, H, W, 3] BGR; None elsewhere): scatter the frames, run this rank's
+        share as one batch, gather the named outputs back on `root` in sequence order (None on the other ranks).  With
+        world == 1 this is process_batch.  Frame ids continue from the previous call like process_batch's."""
+        import torch
+        if self.world == 1:
+            out = self.process_batch(left, right)
+            torch.cuda.current_stream().wait_event(out["done"]) if "done" in out else None
+            return {k: out[k] for k in keys}
+        e = self.engine
+        dev = torch.device("cuda", torch.cuda.current_device())
+        per_frame = (e.height, e.width) if channels == 1 else (e.height, e.width, 3)
+        l = scatter_sequence(left, n_total, (per_frame, torch.uint8, dev), root, self.group)
+        r = scatter_sequence(right, n_total, (per_frame, torch.uint8, dev), root, self.group)
+        out = self.process_batch(l, r)
+        if "done" in out:
+            torch.cuda.current_stream().wait_event(out["done"])
+        return {k: gather_sequence(out[k], root, self.group) for k in keys}
 
     def _process_batch(self, left, right, disp=None):
         """left/right: uint8 [n,h,w(,3)] on the GPU: this rank's n frames of a global batch of

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_lib as O
-from cartslam.pipeline import PlaneParameterSchedule, shard_ids
+from cartslam.pipeline import PlaneParameterSchedule, gather_sequence, scatter_sequence, shard_ids
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -112,3 +112,50 @@ def test_world_size_2_gloo_equals_single_process():
     assert sorted(seen) == list(range(1, world * n_local * steps + 1))
     for fid, params in seen.items():
         assert params == exp[fid - 1], f"frame {fid}"
+
+
+def _sequence_worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        h, w = 6, 10
+        seq = torch.arange(n_total * h * w, dtype=torch.int32).reshape(n_total, h, w).to(torch.uint8) if rank == 0 else None
+        mine = scatter_sequence(seq, n_total, ((h, w), torch.uint8, "cpu"), root=0)
+        ids = shard_ids(1, n_total // world, rank, world)   # frame k (id k + 1) -> rank k mod world
+        full = torch.arange(n_total * h * w, dtype=torch.int32).reshape(n_total, h, w).to(torch.uint8)
+        ok_scatter = all(torch.equal(mine[j], full[i - 1]) for j, i in enumerate(ids))
+        out = (mine.to(torch.int16) * 3 + rank)   # stands in for this rank's outputs
+        back = gather_sequence(out, root=0)
+        ok_gather = True
+        if rank == 0:
+            want = full.to(torch.int16) * 3 + (torch.arange(n_total) % world).to(torch.int16)[:, None, None]
+            ok_gather = torch.equal(back, want)
+        else:
+            ok_gather = back is None
+        bad = None
+        try:
+            scatter_sequence(None, n_total + 1, ((h, w), torch.uint8, "cpu"))
+        except ValueError as e:
+            bad = str(e)
+        q.put((rank, ok_scatter, ok_gather, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_scatter_gather_world_2():
+    """BASELINE configs[4] plumbing: a sequence on rank 0 is dealt out frame k -> rank k mod world and the outputs come
+    back in sequence order; a length that does not divide is refused on every rank before any collective is posted."""
+    world, n_total = 2, 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sequence_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=60) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_scatter, ok_gather, bad in results:
+        assert ok_scatter and ok_gather, rank
+        assert bad and "multiple of the world size" in bad
