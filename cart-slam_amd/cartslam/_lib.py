@@ -48,6 +48,8 @@ PROTOTYPES = {
     "cart_disparity_derivative": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
     "cart_plane_derivative_hist": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _vp]),
     "cart_plane_classify": (_i, [_vp, _i, _vp, _sz, _sz, C.POINTER(PlaneParams), _i, _vp, _sz, _sz, _vp]),
+    "cart_plane_derivative_hist_multi": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    "cart_plane_classify_multi": (_i, [_vp, _i, _vp, _sz, C.POINTER(PlaneParams), _i, _vp, _sz, _vp]),
     "cart_plane_ccl": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
     "cart_plane_ccl_stats": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _i, _vp, _vp]),
     "cart_plane_schedule_create": (_i, [_vp, _i, C.POINTER(PlaneParams), _i, _i, C.POINTER(_vp)]),

@@ -163,6 +163,33 @@ class Engine:
                                                   _stream_ptr()), "cart_plane_classify")
         return planes
 
+    def plane_label_multi(self, disps, hist, params):
+        """Frames in separate allocations (a list of [H,W] int16 disparity tensors with a common row step): plane
+        derivative + cumulative histogram (`hist`: int32 [256], added to) and classification with `params` (one
+        PlaneParams / 6-tuple for all frames, or a list with one per frame), one launch per stage.
+        Returns (list of derivative images, list of plane images)."""
+        import torch
+        n = len(disps)
+        if n == 0:
+            raise EngineError("disps must be a non-empty list")
+        geo = [_geom(t, 1) for t in disps]
+        if any(tuple(t.shape) != (self.height, self.width) or t.dtype != torch.int16 for t in disps) or len({g[2] for g in geo}) != 1:
+            raise EngineError("every disparity image must be int16 HxW with the same row step")
+        if hist.dtype != torch.int32 or not hist.is_contiguous():
+            raise EngineError("hist must be a contiguous int32 tensor")
+        derivs = [torch.empty((self.height, self.width), dtype=torch.int16, device=disps[0].device) for _ in range(n)]
+        planes = [torch.empty((self.height, self.width), dtype=torch.uint8, device=disps[0].device) for _ in range(n)]
+        table = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._check(self._lib.cart_plane_derivative_hist_multi(self._h, n, table(disps), geo[0][2], table(derivs), self.width * 2,
+                                                               C.c_void_p(hist.data_ptr()), 0, _stream_ptr()), "cart_plane_derivative_hist_multi")
+        plist = params if isinstance(params, list) else [params]
+        arr = (PlaneParams * len(plist))()
+        for i, q in enumerate(plist):
+            arr[i] = q if isinstance(q, PlaneParams) else PlaneParams(*q)
+        self._check(self._lib.cart_plane_classify_multi(self._h, n, table(derivs), self.width * 2, arr, 1 if len(plist) == n and n > 1 else 0,
+                                                        table(planes), self.width, _stream_ptr()), "cart_plane_classify_multi")
+        return derivs, planes
+
     def plane_classify_dev(self, deriv, params_dev):
         """params_dev: int32 CUDA tensor [n,6] (one cart_plane_params per frame) or [6] (shared)."""
         import torch

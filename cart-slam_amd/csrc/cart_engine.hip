@@ -593,6 +593,53 @@ int cart_plane_classify(cart_engine *e, int n_frames, const int16_t *deriv, size
     return 0;
 }
 
+int cart_plane_derivative_hist_multi(cart_engine *e, int n_frames, const int16_t *const *disp, size_t disp_step, int16_t *const *out,
+                                     size_t out_step, int32_t *hist256, size_t hist_frame_stride_elems, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!disp || !out || !hist256) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (disp_step < (size_t)g.w * 2 || out_step < (size_t)g.w * 2 || (disp_step & 1) || (out_step & 1)) return fail("bad step");
+    for (int f = 0; f < n_frames; ++f)
+        if (!disp[f] || !out[f]) return fail("NULL image pointer in a pointer table");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    for (int f0 = 0; f0 < n_frames; f0 += kLaunchFrames) {
+        const int n = std::min(kLaunchFrames, n_frames - f0);
+        FrameTable dt{}, ot{};
+        dt.scattered = ot.scattered = 1;
+        for (int f = 0; f < n; ++f) { dt.p[f] = disp[f0 + f]; ot.p[f] = out[f0 + f]; }
+        launch_plane_derivative(nullptr, disp_step, 0, nullptr, out_step, 0, hist256 + (size_t)f0 * hist_frame_stride_elems, hist_frame_stride_elems, g.w, g.h, n,
+                                static_cast<hipStream_t>(stream_), &dt, &ot);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cart_plane_classify_multi(cart_engine *e, int n_frames, const int16_t *const *deriv, size_t deriv_step, const cart_plane_params *params,
+                              int params_per_frame, uint8_t *const *planes, size_t planes_step, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!deriv || !planes || !params) return fail("NULL pointer");
+    if (n_frames <= 0) return fail("n_frames must be positive");
+    const Geometry &g = e->g;
+    if (deriv_step < (size_t)g.w * 2 || planes_step < (size_t)g.w || (deriv_step & 1)) return fail("bad step");
+    for (int f = 0; f < n_frames; ++f)
+        if (!deriv[f] || !planes[f]) return fail("NULL image pointer in a pointer table");
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    static_assert(kMaxBatchArgs >= kLaunchFrames, "one ClassifyParams covers a launch");
+    for (int f0 = 0; f0 < n_frames; f0 += kLaunchFrames) {
+        const int n = std::min(kLaunchFrames, n_frames - f0);
+        ClassifyParams cp;
+        if (params_per_frame) std::memcpy(cp.p, params + f0, sizeof(cart_plane_params) * (size_t)n);
+        else cp.p[0] = params[0];
+        FrameTable dt{}, pt{};
+        dt.scattered = pt.scattered = 1;
+        for (int f = 0; f < n; ++f) { dt.p[f] = deriv[f0 + f]; pt.p[f] = planes[f0 + f]; }
+        launch_classify(nullptr, deriv_step, 0, cp, params_per_frame, nullptr, planes_step, 0, g.w, g.h, n, static_cast<hipStream_t>(stream_), &dt, &pt);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int cart_plane_ccl(cart_engine *e, int n_frames, const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
                    int32_t *ids, size_t ids_step, size_t ids_frame_stride, int32_t *n_components, void *stream_) {
     if (!e) return fail("engine is NULL");

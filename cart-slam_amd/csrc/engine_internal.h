@@ -91,11 +91,16 @@ void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, cons
                         int min_disp16, int max_disp, int n_frames, hipStream_t s);
 void launch_dir_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
                            int32_t *hist512, int w, int h, int n_frames, hipStream_t s);
+// Optional per-launch frame table of the plane kernels: with `scattered` the image of frame f is p[f] instead of
+// base + f * frame_stride (the *_multi entry points: frames in separate allocations).
+struct FrameTable { const void *p[kLaunchFrames]; int scattered; };
 void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
-                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s);
+                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s,
+                             const FrameTable *disp_table = nullptr, const FrameTable *out_table = nullptr);
 struct ClassifyParams { cart_plane_params p[kMaxBatchArgs]; };
 void launch_classify(const int16_t *deriv, size_t step, size_t fs, const ClassifyParams &params, int per_frame,
-                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s);
+                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s,
+                     const FrameTable *deriv_table = nullptr, const FrameTable *planes_table = nullptr);
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
                 int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
 

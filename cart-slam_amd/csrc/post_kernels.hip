@@ -148,13 +148,15 @@ constexpr int PD_ROWS = 8, PD_COPIES = 16, PD_PITCH = 257;
 
 __global__ __launch_bounds__(256) void plane_derivative_kernel(const int16_t *disp, size_t step, size_t fs, int16_t *out,
                                                                size_t ostep, size_t ofs, int32_t *hist256, size_t hist_fs,
-                                                               int w, int h) {
+                                                               int w, int h, FrameTable dtab, FrameTable otab) {
     __shared__ int lh[PD_COPIES * PD_PITCH];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     for (int i = tid; i < PD_COPIES * PD_PITCH; i += 256) lh[i] = 0;
     __syncthreads();
     const int x = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.z;
     const int ybase = blockIdx.y * (4 * PD_ROWS) + threadIdx.y * PD_ROWS;
+    if (dtab.scattered) { disp = static_cast<const int16_t *>(dtab.p[frame]); fs = 0; }
+    if (otab.scattered) { out = static_cast<int16_t *>(const_cast<void *>(otab.p[frame])); ofs = 0; }
     if (x < w && ybase < h) {
         int v[PD_ROWS + 6];   // rows ybase-3 .. ybase+PD_ROWS+2; INVALID where outside the image
 #pragma unroll
@@ -193,16 +195,22 @@ __global__ __launch_bounds__(256) void plane_derivative_kernel(const int16_t *di
 }
 
 void launch_plane_derivative(const int16_t *disp, size_t step, size_t fs, int16_t *out, size_t ostep, size_t ofs,
-                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s) {
+                             int32_t *hist256, size_t hist_fs, int w, int h, int n_frames, hipStream_t s,
+                             const FrameTable *disp_table, const FrameTable *out_table) {
     dim3 grid((w + 63) / 64, (h + 4 * PD_ROWS - 1) / (4 * PD_ROWS), n_frames), block(64, 4);
-    hipLaunchKernelGGL(plane_derivative_kernel, grid, block, 0, s, disp, step, fs, out, ostep, ofs, hist256, hist_fs, w, h);
+    const FrameTable none{};
+    hipLaunchKernelGGL(plane_derivative_kernel, grid, block, 0, s, disp, step, fs, out, ostep, ofs, hist256, hist_fs, w, h,
+                       disp_table ? *disp_table : none, out_table ? *out_table : none);
 }
 
 // ------------------------------------------------------------------ classify
 __global__ __launch_bounds__(256) void classify_kernel(const int16_t *deriv, size_t step, size_t fs, ClassifyParams params,
-                                                       int per_frame, uint8_t *planes, size_t pstep, size_t pfs, int w, int h) {
+                                                       int per_frame, uint8_t *planes, size_t pstep, size_t pfs, int w, int h,
+                                                       FrameTable dtab, FrameTable ptab) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= w || y >= h) return;
+    if (dtab.scattered) { deriv = static_cast<const int16_t *>(dtab.p[frame]); fs = 0; }
+    if (ptab.scattered) { planes = static_cast<uint8_t *>(const_cast<void *>(ptab.p[frame])); pfs = 0; }
     const cart_plane_params pp = params.p[per_frame ? frame : 0];
     const int d = row_ptr(deriv, fs, step, frame, y)[x];
     int plane = CART_PLANE_UNKNOWN;
@@ -212,9 +220,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const int16_t *deriv, siz
 }
 
 void launch_classify(const int16_t *deriv, size_t step, size_t fs, const ClassifyParams &params, int per_frame,
-                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s) {
+                     uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s,
+                     const FrameTable *deriv_table, const FrameTable *planes_table) {
     dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
-    hipLaunchKernelGGL(classify_kernel, grid, block, 0, s, deriv, step, fs, params, per_frame, planes, pstep, pfs, w, h);
+    const FrameTable none{};
+    hipLaunchKernelGGL(classify_kernel, grid, block, 0, s, deriv, step, fs, params, per_frame, planes, pstep, pfs, w, h,
+                       deriv_table ? *deriv_table : none, planes_table ? *planes_table : none);
 }
 
 __global__ __launch_bounds__(256) void classify_dev_kernel(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params,

@@ -96,6 +96,8 @@ class DisparityPlaneSegmentationModule : public SyncWrapperSystemModule {
     int32_t *derivativeHistogram = nullptr;  // persistent 256-bin device histogram (planeseg.hpp:160-161)
     std::mutex engineMutex;
     std::shared_ptr<EngineHandle> engine;
+    std::shared_ptr<class PlaneCoalescer> coalescer;  // frames that wait together share one launch per stage (modules.cpp); NULL when CARTSLAM_COALESCE=0
+    void ensureHistogram();
 };
 
 // mirrors include/modules/planeseg.hpp:164-186 + src/modules/planeseg/sp_planeseg.cu:180-388: per-pixel classification of

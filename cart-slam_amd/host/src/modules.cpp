@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "cartslam_amd/modules/depth.hpp"
@@ -22,29 +23,39 @@ void hipCheck(hipError_t e, const char *what) {
 
 // The reference creates and destroys one stream per invocation (disparity.cu:56, planeseg.cu:279-280,300-301); stream
 // creation costs ~100 us here, so invocations borrow a stream from a pool instead (same concurrency, no churn).
+// Two classes: the disparity module's launches fill the GPU for a millisecond at a time ("bulk", default priority);
+// every other module enqueues short kernels, and on a default-priority stream their workgroups queue behind the whole
+// remaining grid of whatever bulk kernel is resident (a 20 us classify kernel then takes 0.4-0.8 ms).  Those streams
+// get the highest priority, so the dispatcher places their few workgroups as soon as any slot frees up.
+// CARTSLAM_STREAM_PRIORITY=0 puts everything on default-priority streams.
 class StreamPool {
    public:
     static StreamPool &instance() { static StreamPool p; return p; }
-    hipStream_t acquire() {
+    hipStream_t acquire(bool bulk) {
+        std::vector<hipStream_t> &idle = bulk ? idleBulk : idleShort;
         {
             std::lock_guard<std::mutex> lock(mutex);
             if (!idle.empty()) { hipStream_t s = idle.back(); idle.pop_back(); return s; }
         }
+        static const bool usePriority = [] { const char *e = std::getenv("CARTSLAM_STREAM_PRIORITY"); return !e || std::atoi(e) != 0; }();
+        int least = 0, greatest = 0;  // numerically: greatest priority = lowest number
+        hipCheck(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
         hipStream_t s = nullptr;
-        hipCheck(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        hipCheck(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, (bulk || !usePriority) ? least : greatest), "hipStreamCreateWithPriority");
         return s;
     }
-    void release(hipStream_t s) { std::lock_guard<std::mutex> lock(mutex); idle.push_back(s); }
+    void release(hipStream_t s, bool bulk) { std::lock_guard<std::mutex> lock(mutex); (bulk ? idleBulk : idleShort).push_back(s); }
 
    private:
     std::mutex mutex;
-    std::vector<hipStream_t> idle;
+    std::vector<hipStream_t> idleBulk, idleShort;
 };
 
 struct ScopedStream {
     hipStream_t s = nullptr;
-    ScopedStream() : s(StreamPool::instance().acquire()) {}
-    ~ScopedStream() { if (s) StreamPool::instance().release(s); }
+    const bool bulk;
+    explicit ScopedStream(bool bulk = false) : s(StreamPool::instance().acquire(bulk)), bulk(bulk) {}
+    ~ScopedStream() { if (s) StreamPool::instance().release(s, bulk); }
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 
@@ -65,24 +76,27 @@ EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
 EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }
 void EngineHandle::fail(const char *what) const { throw std::runtime_error(std::string(what) + ": " + cart_last_error(engine)); }
 
-// ---------------------------------------------------------------- disparity (disparity.cu:49-80)
+// ---------------------------------------------------------------- frame coalescing
 // The reference's runtime enters runInternal from up to CARTSLAM_CONCURRENT_RUN_LIMIT worker threads at once, one frame
 // each (cartslam.cpp:196).  One frame per launch sequence leaves path aggregation latency-bound on this GPU (0.67 ms per
-// frame against 0.10 ms per frame in a 16-frame launch), so the frames that are waiting at the same moment are handed to
-// the engine as ONE cart_compute_disparity_multi call.  Leader/follower, no extra thread and no timer: a caller whose
-// request is still queued becomes the leader as soon as fewer than `maxOutstanding` groups are on the GPU, takes every
-// compatible queued request, runs the group on its own stream and wakes the others.  A lone frame is dispatched at once
-// (no added latency at low load); groups only form while the GPU is already busy with earlier ones.
-class DisparityCoalescer {
+// frame against 0.10 ms per frame in a 16-frame launch) and a one-frame plane kernel costs what a 16-frame one does, so
+// the frames that are waiting inside a module at the same moment are handed to the engine as ONE *_multi call.
+// Leader/follower, no extra thread and no timer: a caller whose request is still queued becomes the leader as soon as
+// fewer than `maxOutstanding` groups are on the GPU, takes every compatible queued request, runs the group on its own
+// stream and wakes the others.  A lone frame is dispatched at once (no added latency at low load); groups only form
+// while the GPU is already busy with earlier ones.
+struct CoalescedRequest {
+    bool queued = true, done = false;
+    std::string error;
+};
+
+template <class Request>
+class FrameCoalescer {
    public:
-    struct Request {
-        const uint8_t *left, *right; size_t leftStep, rightStep; int channels;
-        int16_t *out; size_t outStep;
-        bool queued = true, done = false;
-        std::string error;
-    };
-    DisparityCoalescer(std::shared_ptr<EngineHandle> engine, int maxGroup, int maxOutstanding)
-        : engine(std::move(engine)), maxGroup(maxGroup), maxOutstanding(maxOutstanding) {}
+    using Compatible = std::function<bool(const Request &, const Request &)>;
+    using RunGroup = std::function<void(const std::vector<Request *> &)>;   // enqueue + wait; throws on failure
+    FrameCoalescer(int maxGroup, int maxOutstanding, Compatible compatible, RunGroup runGroup)
+        : maxGroup(maxGroup), maxOutstanding(maxOutstanding), compatible(std::move(compatible)), runGroup(std::move(runGroup)) {}
 
     void run(Request &rq) {
         std::unique_lock<std::mutex> lock(mutex);
@@ -93,25 +107,14 @@ class DisparityCoalescer {
             std::vector<Request *> group{&rq}, rest;
             for (Request *q : pending) {
                 if (q == &rq) continue;
-                const bool fits = (int)group.size() < maxGroup && q->channels == rq.channels && q->leftStep == rq.leftStep &&
-                                  q->rightStep == rq.rightStep && q->outStep == rq.outStep;
-                (fits ? group : rest).push_back(q);
+                ((int)group.size() < maxGroup && compatible(*q, rq) ? group : rest).push_back(q);
             }
             pending.swap(rest);
             for (Request *q : group) q->queued = false;
             ++outstanding;
             lock.unlock();
             std::string error;
-            try {
-                std::vector<const uint8_t *> lefts, rights;
-                std::vector<int16_t *> outs;
-                for (Request *q : group) { lefts.push_back(q->left); rights.push_back(q->right); outs.push_back(q->out); }
-                ScopedStream stream;
-                if (cart_compute_disparity_multi(engine->get(), (int)group.size(), lefts.data(), rq.leftStep, rights.data(), rq.rightStep, rq.channels,
-                                                 outs.data(), rq.outStep, stream.s) != 0)
-                    error = std::string("cart_compute_disparity_multi: ") + cart_last_error(engine->get());
-                else stream.wait();  // stream.waitForCompletion(), disparity.cu:77
-            } catch (const std::exception &e) { error = e.what(); }
+            try { runGroup(group); } catch (const std::exception &e) { error = e.what(); if (error.empty()) error = "failed"; }
             lock.lock();
             --outstanding;
             ++groups; frames += group.size();
@@ -120,12 +123,13 @@ class DisparityCoalescer {
         }
         if (!rq.error.empty()) throw std::runtime_error(rq.error);
     }
-    // mean frames per launch sequence so far (diagnostics: the timing CSV / tests)
+    // mean frames per launch sequence so far (diagnostics)
     double meanGroup() { std::lock_guard<std::mutex> lock(mutex); return groups ? (double)frames / groups : 0.0; }
 
    private:
-    std::shared_ptr<EngineHandle> engine;
     const int maxGroup, maxOutstanding;
+    const Compatible compatible;
+    const RunGroup runGroup;
     std::mutex mutex;
     std::condition_variable cv;
     std::vector<Request *> pending;
@@ -133,16 +137,47 @@ class DisparityCoalescer {
     size_t groups = 0, frames = 0;
 };
 
+// CARTSLAM_COALESCE = frame groups of one module allowed on the GPU at once (default 2); 0 = one launch sequence per frame
+static int coalesceGroups() {
+    const char *env = std::getenv("CARTSLAM_COALESCE");
+    return env ? std::atoi(env) : 2;
+}
+static int coalesceMaxGroup() { return (int)std::min<size_t>(concurrentRunLimit(), 16); }  // 16 = frames per launch sequence
+
+// ---------------------------------------------------------------- disparity (disparity.cu:49-80)
+struct DisparityRequest : CoalescedRequest {
+    const uint8_t *left, *right; size_t leftStep, rightStep; int channels;
+    int16_t *out; size_t outStep;
+};
+class DisparityCoalescer : public FrameCoalescer<DisparityRequest> {
+   public:
+    using FrameCoalescer<DisparityRequest>::FrameCoalescer;
+};
+
 ImageDisparityModule::ImageDisparityModule(const Size imageRes, int minDisparity, int numDisparities, int /*blockSize: ignored by the CUDA SGM too*/,
                                            int smoothingRadius, int smoothingIterations, int paths, int p1, int p2, int uniquenessRatio)
     : SyncWrapperSystemModule("ImageDisparity"), imageRes(imageRes) {
     this->providesData.push_back(CARTSLAM_KEY_DISPARITY);
-    cart_engine_params params = paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio);
-    // CARTSLAM_COALESCE = number of frame groups allowed on the GPU at once (default 2); 0 = one launch sequence per frame
-    const char *env = std::getenv("CARTSLAM_COALESCE");
-    const int outstanding = env ? std::atoi(env) : 2;
-    engine = std::make_shared<EngineHandle>(imageRes, params);
-    if (outstanding > 0) coalescer = std::make_shared<DisparityCoalescer>(engine, std::min(params.max_inflight, 16), outstanding);  // 16 = frames per launch sequence
+    engine = std::make_shared<EngineHandle>(imageRes, paramsFor(imageRes, minDisparity, numDisparities, smoothingRadius, smoothingIterations, paths, p1, p2, uniquenessRatio));
+    if (coalesceGroups() > 0) {
+        auto eng = engine;
+        coalescer = std::make_shared<DisparityCoalescer>(
+            coalesceMaxGroup(), coalesceGroups(),
+            [](const DisparityRequest &a, const DisparityRequest &b) {
+                return a.channels == b.channels && a.leftStep == b.leftStep && a.rightStep == b.rightStep && a.outStep == b.outStep;
+            },
+            [eng](const std::vector<DisparityRequest *> &group) {
+                std::vector<const uint8_t *> lefts, rights;
+                std::vector<int16_t *> outs;
+                for (const DisparityRequest *q : group) { lefts.push_back(q->left); rights.push_back(q->right); outs.push_back(q->out); }
+                const DisparityRequest &rq = *group[0];
+                ScopedStream stream(true);
+                if (cart_compute_disparity_multi(eng->get(), (int)group.size(), lefts.data(), rq.leftStep, rights.data(), rq.rightStep, rq.channels,
+                                                 outs.data(), rq.outStep, stream.s) != 0)
+                    eng->fail("cart_compute_disparity_multi");
+                stream.wait();  // stream.waitForCompletion(), disparity.cu:77
+            });
+    }
 }
 
 double ImageDisparityModule::meanFramesPerLaunch() const { return coalescer ? coalescer->meanGroup() : 1.0; }
@@ -159,11 +194,13 @@ system_data_t ImageDisparityModule::runInternal(System &, SystemRunData &data) {
                                  std::to_string(imageRes.width) + "x" + std::to_string(imageRes.height));
     auto disparity = std::make_shared<image_t>(l.rows, l.cols, CV_16SC1);
     if (coalescer) {
-        DisparityCoalescer::Request rq{l.ptr<uint8_t>(), r.ptr<uint8_t>(), l.step, r.step, channels, disparity->ptr<int16_t>(), disparity->step};
+        DisparityRequest rq;
+        rq.left = l.ptr<uint8_t>(); rq.right = r.ptr<uint8_t>(); rq.leftStep = l.step; rq.rightStep = r.step; rq.channels = channels;
+        rq.out = disparity->ptr<int16_t>(); rq.outStep = disparity->step;
         coalescer->run(rq);
         return MODULE_RETURN(CARTSLAM_KEY_DISPARITY, disparity);
     }
-    ScopedStream stream;
+    ScopedStream stream(true);
     if (cart_compute_disparity(engine->get(), l.ptr<uint8_t>(), l.step, r.ptr<uint8_t>(), r.step, channels, disparity->ptr<int16_t>(), disparity->step, stream.s) != 0)
         engine->fail("cart_compute_disparity");
     stream.wait();  // stream.waitForCompletion(), disparity.cu:77
@@ -244,34 +281,92 @@ DisparityPlaneSegmentationModule::~DisparityPlaneSegmentationModule() {
     if (derivativeHistogram) (void)hipFree(derivativeHistogram);
 }
 
+struct PlaneRequest : CoalescedRequest {
+    const int16_t *disparity; size_t disparityStep;
+    int16_t *derivatives; size_t derivativesStep;
+    uint8_t *planes; size_t planesStep;
+};
+class PlaneCoalescer : public FrameCoalescer<PlaneRequest> {
+   public:
+    using FrameCoalescer<PlaneRequest>::FrameCoalescer;
+};
+
+void DisparityPlaneSegmentationModule::ensureHistogram() {
+    static std::mutex createMutex;
+    std::lock_guard<std::mutex> lk(createMutex);
+    if (!derivativeHistogram) {
+        hipCheck(hipMalloc(reinterpret_cast<void **>(&derivativeHistogram), 256 * sizeof(int32_t)), "hipMalloc");
+        hipCheck(hipMemset(derivativeHistogram, 0, 256 * sizeof(int32_t)), "hipMemset");
+    }
+}
+
 system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, SystemRunData &data) {
     auto disparity = data.getData<image_t>(CARTSLAM_KEY_DISPARITY);
     if (disparity->empty()) return MODULE_NO_RETURN_VALUE;  // planeseg.cu:250-253
     if (disparity->type() != CV_16SC1) throw std::runtime_error("Disparity must be of type CV_16SC1");
     auto eng = postEngine(engineMutex, engine, *disparity);
     auto derivatives = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_16SC1);
-    {
-        std::shared_lock<std::shared_mutex> lock(derivativeHistogramMutex);  // read-lock section, planeseg.cu:269-288
+    const bool updateFrame = (int)(data.id % (uint32_t)this->updateInterval) == 1;
+    // Frames that neither refresh the parameters nor need per-frame extras go through the coalescer: the frames waiting
+    // here together get one derivative launch (all adding to the cumulative histogram, like concurrent frames of the
+    // reference do) and one classify launch with the parameters current at that moment.
+    if (!updateFrame && !this->useTemporalSmoothing && !this->labelComponents && coalesceGroups() > 0) {
         {
-            static std::mutex createMutex;
-            std::lock_guard<std::mutex> lk(createMutex);
-            if (!derivativeHistogram) {
-                hipCheck(hipMalloc(reinterpret_cast<void **>(&derivativeHistogram), 256 * sizeof(int32_t)), "hipMalloc");
-                hipCheck(hipMemset(derivativeHistogram, 0, 256 * sizeof(int32_t)), "hipMemset");
+            std::lock_guard<std::mutex> lk(engineMutex);
+            if (!coalescer) {
+                coalescer = std::make_shared<PlaneCoalescer>(
+                    coalesceMaxGroup(), coalesceGroups(),
+                    [](const PlaneRequest &a, const PlaneRequest &b) {
+                        return a.disparityStep == b.disparityStep && a.derivativesStep == b.derivativesStep && a.planesStep == b.planesStep;
+                    },
+                    [this, eng](const std::vector<PlaneRequest *> &group) {
+                        std::shared_lock<std::shared_mutex> histogramLock(derivativeHistogramMutex);  // until the group's kernels have finished
+                        ensureHistogram();
+                        std::vector<const int16_t *> disps, derivsIn;
+                        std::vector<int16_t *> derivs;
+                        std::vector<uint8_t *> labels;
+                        for (const PlaneRequest *q : group) { disps.push_back(q->disparity); derivs.push_back(q->derivatives); derivsIn.push_back(q->derivatives); labels.push_back(q->planes); }
+                        const PlaneRequest &rq = *group[0];
+                        ScopedStream stream;
+                        if (cart_plane_derivative_hist_multi(eng->get(), (int)group.size(), disps.data(), rq.disparityStep, derivs.data(), rq.derivativesStep,
+                                                             derivativeHistogram, 0, stream.s) != 0)
+                            eng->fail("cart_plane_derivative_hist_multi");
+                        const PlaneParameters pp = planeParameterProvider->getPlaneParameters();
+                        cart_plane_params cp{pp.horizontalRange.first, pp.horizontalRange.second, pp.verticalRange.first, pp.verticalRange.second, pp.horizontalCenter, pp.verticalCenter};
+                        if (cart_plane_classify_multi(eng->get(), (int)group.size(), derivsIn.data(), rq.derivativesStep, &cp, 0, labels.data(), rq.planesStep, stream.s) != 0)
+                            eng->fail("cart_plane_classify_multi");
+                        stream.wait();
+                    });
             }
         }
-        ScopedStream stream;
-        if (cart_plane_derivative_hist(eng->get(), 1, disparity->ptr<int16_t>(), disparity->step, 0, derivatives->ptr<int16_t>(), derivatives->step, 0,
-                                       derivativeHistogram, 0, stream.s) != 0)
-            eng->fail("cart_plane_derivative_hist");
-        stream.wait();
+        auto planes = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_8UC1);
+        PlaneRequest rq;
+        rq.disparity = disparity->ptr<int16_t>(); rq.disparityStep = disparity->step;
+        rq.derivatives = derivatives->ptr<int16_t>(); rq.derivativesStep = derivatives->step;
+        rq.planes = planes->ptr<uint8_t>(); rq.planesStep = planes->step;
+        coalescer->run(rq);
+        return MODULE_RETURN(CARTSLAM_KEY_PLANES, planes);
     }
-    this->updatePlaneParameters(system, data);
+    // Read-lock section, planeseg.cu:269-288: the histogram download of an update frame (unique lock) must not overlap a
+    // derivative kernel that is still adding to it.  An update frame (id % updateInterval == 1) synchronises and
+    // releases the lock right after its derivative kernel, like the reference; every other frame has nothing to do
+    // between the two kernels, keeps the lock and enqueues the rest of the module behind the derivative kernel on the
+    // same stream: one stream synchronisation per frame instead of two.
+    std::shared_lock<std::shared_mutex> histogramLock(derivativeHistogramMutex);
+    ensureHistogram();
+    ScopedStream stream;
+    if (cart_plane_derivative_hist(eng->get(), 1, disparity->ptr<int16_t>(), disparity->step, 0, derivatives->ptr<int16_t>(), derivatives->step, 0,
+                                   derivativeHistogram, 0, stream.s) != 0)
+        eng->fail("cart_plane_derivative_hist");
+    if (updateFrame) {
+        stream.wait();
+        histogramLock.unlock();
+        this->updatePlaneParameters(system, data);
+    }
 
     auto planes = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_8UC1);
     const PlaneParameters pp = planeParameterProvider->getPlaneParameters();
     cart_plane_params cp{pp.horizontalRange.first, pp.horizontalRange.second, pp.verticalRange.first, pp.verticalRange.second, pp.horizontalCenter, pp.verticalCenter};
-    ScopedStream stream;
     if (cart_plane_classify(eng->get(), 1, derivatives->ptr<int16_t>(), derivatives->step, 0, &cp, 0, planes->ptr<uint8_t>(), planes->step, 0, stream.s) != 0)
         eng->fail("cart_plane_classify");
     std::shared_ptr<image_t> smoothed;

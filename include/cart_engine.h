@@ -124,6 +124,19 @@ int cart_plane_classify(cart_engine *engine, int n_frames,
                         const cart_plane_params *params, int params_per_frame,
                         uint8_t *planes, size_t planes_step, size_t planes_frame_stride, void *stream);
 
+/* cart_plane_derivative_hist / cart_plane_classify for frames in separate allocations (host arrays of n_frames device
+ * pointers, read before the call returns; one step per image kind): what a module adapter uses to serve the frames that
+ * wait inside DisparityPlaneSegmentationModule::runInternal at the same moment with one launch per stage -- a one-frame
+ * launch of these kernels costs 25-55 us of GPU time, a 16-frame launch 16-23 us.  hist_frame_stride_elems as above
+ * (0: every frame adds to the one persistent histogram); params_per_frame: 0 = params[0] for all, 1 = params[f]. */
+int cart_plane_derivative_hist_multi(cart_engine *engine, int n_frames,
+                                     const int16_t *const *disp, size_t disp_step, int16_t *const *out, size_t out_step,
+                                     int32_t *hist256, size_t hist_frame_stride_elems, void *stream);
+int cart_plane_classify_multi(cart_engine *engine, int n_frames,
+                              const int16_t *const *deriv, size_t deriv_step,
+                              const cart_plane_params *params, int params_per_frame,
+                              uint8_t *const *planes, size_t planes_step, void *stream);
+
 /* replaces: the temporal-voting branch of classifyPlanes (planeseg.cu:199-240) with the tables the module builds at
  * :303-347: prev_planes[k] = unsmoothed planes of frame id-(k+1), flows[k] = optical flow of frame id-k (CV_16SC2-shaped,
  * S10.5 fixed point).  n_prev <= 8.  The pointer arrays are HOST arrays of DEVICE pointers.  Single frame: temporal

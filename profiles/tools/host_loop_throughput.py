@@ -8,7 +8,7 @@ from cartslam import synth
 tmp = os.environ.get("PREPARE_ONLY") or tempfile.mkdtemp(dir="/tmp")  # PREPARE_ONLY=<dir>: write the data set + the four module lists there and stop
 os.makedirs(tmp, exist_ok=True)
 d = os.path.join(tmp, "ds", "sequences", "00"); os.makedirs(d + "/image_2"); os.makedirs(d + "/image_3")
-n = 240
+n = int(os.environ.get("N", 240))   # frames 4.. are hard links to the four distinct pairs
 base = [synth.make_pair(1242, 375, 128, 4, frame=f) for f in range(4)]
 SP = [{"type": "superpixels", "initial_iterations": 24, "iterations": 8, "block_size": 12, "reset_iterations": 64},
       {"type": "disparity", "smoothing_radius": 2, "smoothing_iterations": 1}, {"type": "disparity_derivative"}, {"type": "depth"},
@@ -16,6 +16,9 @@ SP = [{"type": "superpixels", "initial_iterations": 24, "iterations": 8, "block_
 for f in range(n):
     l, r, _ = base[f % 4]
     for cam, img in ((2, l), (3, r)):
+        if f >= 4:
+            os.link(f"{d}/image_{cam}/{f % 4:06d}.pgm", f"{d}/image_{cam}/{f:06d}.pgm")
+            continue
         with open(f"{d}/image_{cam}/{f:06d}.pgm", "wb") as fh:
             fh.write(b"P5\n1242 375\n255\n"); fh.write(img.tobytes())
 json.dump({"type": "kitti", "path": os.path.join(tmp, "ds"), "sequence": 0}, open(tmp + "/src.json", "w"))

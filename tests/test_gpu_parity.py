@@ -706,3 +706,31 @@ def test_multi_equals_batch(channels, n):
         assert (store[f][2][:, w:] == -7).all()   # nothing written past the row
     with pytest.raises(EngineError):
         eng.compute_disparity_multi(lefts, rights[:-1])
+
+
+@pytest.mark.gpu
+def test_plane_multi_equals_batch():
+    """cart_plane_derivative_hist_multi + cart_plane_classify_multi on 21 separately allocated frames (two launch
+    sequences) = the strided entry points on the same frames: derivative images, cumulative histogram, labels."""
+    import torch
+    from cartslam import Engine
+    w, h, n = 333, 77, 21
+    eng = Engine(w, h, num_disparities=64, paths=4, max_inflight=n)
+    rng = np.random.default_rng(11)
+    disp = rng.integers(40, 1200, (n, h, w)).astype(np.int16)
+    disp[rng.random((n, h, w)) < 0.05] = -32768
+    disp = np.sort(disp, axis=1)[:, ::-1].copy()   # mostly monotone columns: derivatives land inside the histogram range
+    D = torch.from_numpy(disp).cuda()
+    params = [(2 + f % 3, 40, -30, 2 + f % 3, 20, -10) for f in range(n)]
+    hist_a = torch.zeros(256, dtype=torch.int32, device="cuda")
+    want_d = eng.plane_derivative_hist(D, hist_a)
+    want_p = eng.plane_classify(want_d, params)
+    hist_b = torch.zeros(256, dtype=torch.int32, device="cuda")
+    padded = [torch.nn.functional.pad(D[f], (0, 9)) for f in range(n)]   # a wider row step than the image
+    got_d, got_p = eng.plane_label_multi([t[:, :w] for t in padded], hist_b, params)
+    torch.cuda.synchronize()
+    assert torch.equal(hist_a, hist_b) and int(hist_a.sum()) > 0
+    for f in range(n):
+        assert torch.equal(got_d[f], want_d[f]) and torch.equal(got_p[f], want_p[f]), f
+    one = eng.plane_label_multi([D[3]], torch.zeros(256, dtype=torch.int32, device="cuda"), params[3])
+    assert torch.equal(one[1][0], want_p[3])
