@@ -36,7 +36,34 @@ __device__ __forceinline__ void load_u32s(const uint32_t *p, uint32_t (&r)[N]) {
 // resets the packed right-view minima.
 constexpr int CT_W = 64, CT_H = 16, CT_LW = CT_W + 8, CT_LH = CT_H + 6, CT_PITCH = 76;  // bytes; 19 dwords per row
 
-__device__ __forceinline__ uint32_t win_byte(const uint32_t (&w)[3], int c) { return (w[c >> 2] >> (8 * (c & 3))) & 0xffu; }
+// One census bit: f = 2 f + (byte SA of a > byte SB of b).  The byte selects ride on the compare (SDWA) and the bit enters
+// through the carry of v_addc, so a comparison costs two VALU instructions instead of two extracts, a compare and a
+// shift-or (the kernel is VALU-bound: 124 comparisons per thread).
+#define CART_CENSUS_BIT(SA, SB)                                                                                        \
+    asm("v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:BYTE_" #SA " src1_sel:BYTE_" #SB "\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" \
+        : "+v"(f) : "v"(a), "v"(b) : "vcc")
+// Stores at less than natural alignment (HSA runs the memory pipeline in unaligned mode; with the alignment spelled out
+// the compiler emits one global_store_dword / _dwordx4 instead of splitting into bytes / dwords).
+struct __attribute__((packed, aligned(1))) U32A1 { uint32_t v; };
+struct __attribute__((packed, aligned(4))) U128A4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ void census_bit(uint32_t &f, uint32_t a, int sa, uint32_t b, int sb) {
+    switch (sa * 4 + sb) {   // constant after unrolling
+        case 0: CART_CENSUS_BIT(0, 0); break;   case 1: CART_CENSUS_BIT(0, 1); break;
+        case 2: CART_CENSUS_BIT(0, 2); break;   case 3: CART_CENSUS_BIT(0, 3); break;
+        case 4: CART_CENSUS_BIT(1, 0); break;   case 5: CART_CENSUS_BIT(1, 1); break;
+        case 6: CART_CENSUS_BIT(1, 2); break;   case 7: CART_CENSUS_BIT(1, 3); break;
+        case 8: CART_CENSUS_BIT(2, 0); break;   case 9: CART_CENSUS_BIT(2, 1); break;
+        case 10: CART_CENSUS_BIT(2, 2); break;  case 11: CART_CENSUS_BIT(2, 3); break;
+        case 12: CART_CENSUS_BIT(3, 0); break;  case 13: CART_CENSUS_BIT(3, 1); break;
+        case 14: CART_CENSUS_BIT(3, 2); break;  default: CART_CENSUS_BIT(3, 3); break;
+    }
+}
+#undef CART_CENSUS_BIT
+// bit = I(window column ca of row registers wa) > I(window column cb of wb)
+__device__ __forceinline__ void census_cmp(uint32_t &f, const uint32_t (&wa)[3], int ca, const uint32_t (&wb)[3], int cb) {
+    census_bit(f, wa[ca >> 2], ca & 3, wb[cb >> 2], cb & 3);
+}
 
 __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch right, int channels,
                                                      uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l,
@@ -53,7 +80,43 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < CT_LH * CT_LW; i += 256) {
+    // gray input: the tile is 18 dwords x 22 rows, fetched as the two aligned dwords that cover each element's four bytes
+    // (rows of a 1242-wide image start at 2 mod 4) and funnel-shifted, then one LDS dword store -- two rounds of the block
+    // instead of seven rounds of byte loads and byte stores.  Elements within 8 bytes of a row end are assembled bytewise:
+    // the aligned pair never reaches outside the row it belongs to.  Interior elements also carry the gray copy the post
+    // stage reads.
+    const bool dwords = channels == 1;
+    if (dwords) {
+        for (int i = tid; i < CT_LH * (CT_LW / 4); i += 256) {
+            const int ty = i / (CT_LW / 4), k = i - ty * (CT_LW / 4);
+            const int gx = x0 - 4 + 4 * k, gy = y0 - 3 + ty;
+            uint32_t v = 0;
+            if (gy >= 0 && gy < g.h && gx + 3 >= 0 && gx < g.w) {
+                const uint8_t *row = src + (size_t)gy * img_step;
+                if (gx >= 4 && gx + 8 <= g.w) {
+                    const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(row + gx) & 3u;   // pointer arithmetic keeps the global address space
+                    const uint32_t *ap = reinterpret_cast<const uint32_t *>(row + gx - a);
+                    v = __builtin_amdgcn_alignbyte(ap[1], ap[0], a);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (gx + b >= 0 && gx + b < g.w) v |= (uint32_t)row[gx + b] << (8 * b);
+                }
+                if (k >= 1 && k < 1 + CT_W / 4 && ty >= 3 && ty < 3 + CT_H) {
+                    uint8_t *gp = gray + (size_t)gy * g.w + gx;
+                    if (gx + 3 < g.w) {
+                        reinterpret_cast<U32A1 *>(gp)->v = v;
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            if (gx + b < g.w) gp[b] = (uint8_t)(v >> (8 * b));
+                    }
+                }
+            }
+            *reinterpret_cast<uint32_t *>(tile + ty * CT_PITCH + 4 * k) = v;
+        }
+    }
+    for (int i = tid; i < (dwords ? 0 : CT_LH * CT_LW); i += 256) {
         const int ty = i / CT_LW, tx = i - ty * CT_LW;
         const int gx = x0 - 4 + tx, gy = y0 - 3 + ty;
         uint32_t v = 0;
@@ -87,20 +150,31 @@ __global__ __launch_bounds__(256) void census_kernel(ImageBatch left, ImageBatch
 #pragma unroll
         for (int dx = -4; dx <= 4; ++dx)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                f[i] = (f[i] << 1) | (uint32_t)(win_byte(w[3 + dy], 4 + i + dx) > win_byte(w[3 - dy], 4 + i - dx));
+            for (int i = 0; i < 4; ++i) census_cmp(f[i], w[3 + dy], 4 + i + dx, w[3 - dy], 4 + i - dx);
 #pragma unroll
     for (int dx = -4; dx < 0; ++dx)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = (f[i] << 1) | (uint32_t)(win_byte(w[3], 4 + i + dx) > win_byte(w[3], 4 + i - dx));
+        for (int i = 0; i < 4; ++i) census_cmp(f[i], w[3], 4 + i + dx, w[3], 4 + i - dx);
     const bool yin = y >= 3 && y < g.h - 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = xb + i;
-        if (x >= g.w) break;
-        const bool inner = yin && x >= 4 && x < g.w - 4;  // oracle S2: border features are 0
-        cen[(size_t)y * g.cpitch + g.cpadl + x] = inner ? f[i] : 0u;
-        if (side == 0) right_pk[(size_t)frame * g.npx + (size_t)y * g.w + x] = 0xffffffffu;
+    for (int i = 0; i < 4; ++i) f[i] &= (yin && xb + i >= 4 && xb + i < g.w - 4) ? 0xffffffffu : 0u;  // oracle S2: border features are 0
+    uint32_t *crow = cen + (size_t)y * g.cpitch + g.cpadl + xb;    // cpitch, cpadl, xb are multiples of 4: 16-byte aligned
+    if (xb + 3 < g.w) {
+        *reinterpret_cast<uint4 *>(crow) = make_uint4(f[0], f[1], f[2], f[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (xb + i < g.w) crow[i] = f[i];
+    }
+    if (side == 0) {
+        uint32_t *rp = right_pk + (size_t)frame * g.npx + (size_t)y * g.w + xb;
+        if (xb + 3 < g.w) {
+            *reinterpret_cast<U128A4 *>(rp) = U128A4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xb + i < g.w) rp[i] = 0xffffffffu;
+        }
     }
 }
 
