@@ -1091,40 +1091,57 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_
 }
 
 // ------------------------------------------------------------------ median x2 + LR check + range fix
-#define CART_SORT2(a, b) { const uint32_t _t = min(a, b); b = max(a, b); a = _t; }
-__device__ __forceinline__ uint32_t median9(uint32_t (&p)[9]) {
-    CART_SORT2(p[1], p[2]) CART_SORT2(p[4], p[5]) CART_SORT2(p[7], p[8])
-    CART_SORT2(p[0], p[1]) CART_SORT2(p[3], p[4]) CART_SORT2(p[6], p[7])
-    CART_SORT2(p[1], p[2]) CART_SORT2(p[4], p[5]) CART_SORT2(p[7], p[8])
-    CART_SORT2(p[0], p[3]) CART_SORT2(p[5], p[8]) CART_SORT2(p[4], p[7])
-    CART_SORT2(p[3], p[6]) CART_SORT2(p[1], p[4]) CART_SORT2(p[2], p[5])
-    CART_SORT2(p[4], p[7]) CART_SORT2(p[4], p[2]) CART_SORT2(p[6], p[4])
-    CART_SORT2(p[4], p[2])
-    return p[4];
+// Median of 9 from sorted columns: with every 3-element column sorted into (lo, mid, hi),
+//   median9 = med3( max3(lo0, lo1, lo2), med3(mid0, mid1, mid2), min3(hi0, hi1, hi2) ).
+// A column costs three instructions (v_min3 / v_med3 / v_max3), a median four more, and adjacent pixels share columns.
+__device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct SortedCol { uint32_t lo, mid, hi; };
+__device__ __forceinline__ SortedCol sort_col(uint32_t a, uint32_t b, uint32_t c) {
+    return SortedCol{min(min(a, b), c), med3u(a, b, c), max(max(a, b), c)};
+}
+__device__ __forceinline__ uint32_t median_cols(const SortedCol &c0, const SortedCol &c1, const SortedCol &c2) {
+    return med3u(max(max(c0.lo, c1.lo), c2.lo), med3u(c0.mid, c1.mid, c2.mid), min(min(c0.hi, c1.hi), c2.hi));
 }
 
-template <typename T>
-__device__ __forceinline__ uint32_t median_at(const T *img, int x, int y, int w, int h) {
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return (uint32_t)img[(size_t)y * w + x] & 0xffffu;  // S7 border
-    uint32_t v[9];
+// S7 median of the packed right view (low 16 bits) at (x, y); the image border keeps its own value
+__device__ __forceinline__ uint32_t right_median_at(const uint32_t *img, int x, int y, int w, int h) {
+    const uint32_t *p = img + (size_t)y * w + x;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return p[0] & 0xffffu;
+    SortedCol c[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) v[i] = (uint32_t)img[(size_t)(y - 1 + i / 3) * w + (x - 1 + i % 3)] & 0xffffu;
-    return median9(v);
+    for (int k = 0; k < 3; ++k) c[k] = sort_col(p[k - 1 - w] & 0xffffu, p[k - 1] & 0xffffu, p[k - 1 + w] & 0xffffu);
+    return median_cols(c[0], c[1], c[2]);
 }
 
+// S7 median of the left WTA map at (x, y); the image border keeps its own value
+__device__ __forceinline__ uint32_t left_median_at(const uint16_t *img, int x, int y, int w, int h) {
+    const uint16_t *p = img + (size_t)y * w + x;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return p[0];
+    SortedCol c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = sort_col(p[k - 1 - w], p[k - 1], p[k - 1 + w]);
+    return median_cols(c[0], c[1], c[2]);
+}
+
+// One pixel per thread: the right-view median is a gather at x - d, so the launch wants as many independent threads as
+// it can get (four pixels per thread with shared left columns measured 50 % slower).
 __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const uint32_t *right_pk,
                                                    const uint8_t *gray_l, OutBatch out, Geometry g) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= g.w || y >= g.h) return;
     const uint16_t *wl = wta_l + (size_t)frame * g.npx;
     const uint32_t *rp = right_pk + (size_t)frame * g.npx;
-    const uint32_t ml = median_at(wl, x, y, g.w, g.h);
+    const uint32_t ml = left_median_at(wl, x, y, g.w, g.h);
     bool invalid = gray_l[(size_t)frame * g.npx + (size_t)y * g.w + x] == 0 || ml == kWtaInvalid;
     if (!invalid) {
         const int d = (int)(ml >> 4);
         const int k = x - d;
         if (k >= 0 && k < g.w) {
-            const int mr = (int)median_at(rp, k, y, g.w, g.h);
+            const int mr = (int)right_median_at(rp, k, y, g.w, g.h);
             if (abs(mr - d) > 1) invalid = true;
         }
     }
