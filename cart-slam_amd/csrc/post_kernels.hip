@@ -651,6 +651,6 @@ void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int
                        (const int32_t *)slot, table, max_components, w, h, npx);
 }
 
-int kernel_count() { return 42; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 16 + superpixel_kernels 8 + flow 3
+int kernel_count() { return 43; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 17 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd
