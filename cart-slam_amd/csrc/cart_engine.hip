@@ -299,6 +299,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     }
     if (const char *f = std::getenv("CART_FUSED_WTA")) e->fused_min_frames = std::atoi(f) == 0 ? 1 << 30 : std::min(e->fused_min_frames, 8);
     if (const char *f = std::getenv("CART_FUSED_MIN_FRAMES")) e->fused_min_frames = std::max(1, std::atoi(f));
+    if (const char *f = std::getenv("CART_CHUNK_FRAMES")) e->chunk_frames = std::max(1, std::atoi(f));  // experiments: frames per launch sequence (strided batches only)
     *out = e;
     return 0;
 }
@@ -468,7 +469,8 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     // Large batches run as cache-sized sub-batches on the caller's stream: the census planes every direction
     // re-reads (4.2 MB per frame) then stay in L2 + Infinity Cache (measured: 64 frames in one launch are 13 %
     // slower per frame than 4 x 16).  Two-stream overlap of sub-batches was measured and buys nothing.
-    for (int f0 = 0; f0 < n_frames; f0 += e->chunk_frames) enqueue(f0, std::min(e->chunk_frames, n_frames - f0), stream, f0 == 0);
+    const int chunk = fr.lefts ? std::min(e->chunk_frames, kLaunchFrames) : e->chunk_frames;  // pointer tables hold kLaunchFrames entries
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) enqueue(f0, std::min(chunk, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
     release(l);
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
