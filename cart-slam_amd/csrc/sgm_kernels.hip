@@ -382,12 +382,58 @@ __device__ __forceinline__ void win_read(const uint32_t *lds_buf, int base_slot,
 }
 
 // 6 waves per SIMD (<= 80 VGPRs) fit without spills for D >= 128; the D = 64 variant carries 15 lane offsets more
+// ---- horizontal scans with a sliding right-feature window --------------------------------------------------------
+// Along a row the lane's 16 right features move by ONE element per step, so the window lives in 16 registers that are
+// renamed instead of reloaded (a 16-step group is unrolled; logical slot k of sub-step j is register (k + j*DX) & 15)
+// and a step loads two dwords -- the left feature and the entering right feature -- instead of 17.  Those two come from
+// a FIFO filled HS_PF steps ahead: a horizontal wave is alone on its SIMD for most of its 1242 steps, nothing else hides
+// the load latency, and with the two-step prefetch of the reloading loop every step waited for memory (0.75 us per step
+// against 0.2 us of issue time).  The first group is peeled so that the loop header merges two identical VMEM
+// histories (counted s_waitcnt, see the NOTE in aggregate_kernel).
+constexpr int HS_PF = 8;
+template <int LPP, int DX>
+__device__ __forceinline__ void hscan_sliding(uint32_t (&st)[8], uint32_t &mm, const uint32_t *&pl, unsigned &lo_l, const uint32_t *&pr,
+                                              unsigned &lo_r, uint8_t *&po, unsigned &lo_o, ptrdiff_t ostride, int groups, uint32_t sel_lo,
+                                              uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2) {
+    uint32_t win[16], ffl[HS_PF], fnw[HS_PF], xr[16];
+    ld_u32x16(pr, lo_r, win);                          // window of step 0
+    unsigned lo_n = lo_r + (DX > 0 ? 15u * 4u : 0u);   // the element that enters the window: slot 15 going right, slot 0 going left
+#pragma unroll
+    for (int q = 0; q < HS_PF; ++q) {                  // FIFO entry q: left feature of step q, entering element of step q + 1
+        ffl[q] = ld_u32(pl + q * DX, lo_l);
+        fnw[q] = ld_u32(pr + (q + 1) * DX, lo_n);
+    }
+    auto group = [&]() {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            constexpr int M = 15;
+            const int slot = j % HS_PF;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xr[k] = ffl[slot] ^ win[(DX > 0 ? k + j : k - j + 16) & M];
+            win[(DX > 0 ? j : 15 - j) & M] = fnw[slot];
+            __builtin_amdgcn_sched_barrier(0);
+            ffl[slot] = ld_u32(pl + (j + HS_PF) * DX, lo_l);          // step j + HS_PF (reads row padding past the end)
+            fnw[slot] = ld_u32(pr + (j + HS_PF + 1) * DX, lo_n);
+            __builtin_amdgcn_sched_barrier(0);
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + j * ostride) + pin_v(lo_o));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pl += 16 * DX; pr += 16 * DX; po += 16 * ostride;
+    };
+    group();
+    for (int gi = 1; gi < groups; ++gi) group();
+}
+
+#ifndef CART_AGG_WAVES
+#define CART_AGG_WAVES 4
+#endif
+constexpr int kAggWaves = CART_AGG_WAVES;   // waves per workgroup: nothing in the kernel is shared between waves
 template <int LPP>
-__global__ __launch_bounds__(256, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
+__global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
     using WN = Win<LPP>;
     constexpr int P = WN::P;
-    constexpr int LINES_PER_BLOCK = 4 * P;
-    __shared__ uint32_t s_win[4][2][WN::BUF];
+    constexpr int LINES_PER_BLOCK = kAggWaves * P;
+    __shared__ uint32_t s_win[kAggWaves][2][WN::BUF];
     const Geometry &g = a.g;
     // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
     // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
@@ -438,10 +484,17 @@ __global__ __launch_bounds__(256, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArg
         const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
         const uint32_t *pl = pl_u, *pr = pr_u;
         uint8_t *po = po_u;
+        // full 16-step groups with the sliding window; the last w % 16 steps (and images narrower than a group) through
+        // the reloading loop below, which can start anywhere
+        const int groups = t1 / 16;
+        if (groups > 0) {
+            if (dx > 0) hscan_sliding<LPP, 1>(st, mm, pl, lo_l, pr, lo_r, po, lo_o, ostride, groups, sel_lo, sel_hi, p1p1, p2p2);
+            else hscan_sliding<LPP, -1>(st, mm, pl, lo_l, pr, lo_r, po, lo_o, ostride, groups, sel_lo, sel_hi, p1p1, p2p2);
+        }
         uint32_t xr[16];
         load_census(pl, lo_l, pr, lo_r, ca);
         load_census(pl + cstride, lo_l, pr + cstride, lo_r, cb);
-        int t = 0;
+        int t = groups * 16;
         for (; t + 1 < t1; t += 2) {
             agg_xor(ca, xr);
             __builtin_amdgcn_sched_barrier(0);
@@ -572,12 +625,12 @@ __global__ __launch_bounds__(256, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArg
     ragged(tm1, te);
 }
 
-int agg_lines_per_block(int D) { return 256 / (D / 16); }
+int agg_lines_per_block(int D) { return 64 * kAggWaves / (D / 16); }
 
 void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     AggArgs a = a_in;
     a.n_frames = n_frames;
-    dim3 grid(a.blocks_per_frame * n_frames), block(256);
+    dim3 grid(a.blocks_per_frame * n_frames), block(64 * kAggWaves);
     switch (a.g.D) {
         case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, 0, s, a); break;
         case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, 0, s, a); break;
