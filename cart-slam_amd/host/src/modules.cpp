@@ -473,9 +473,12 @@ system_data_t SuperPixelModule::runInternal(System &, SystemRunData &data) {
     const unsigned int numIterations = (data.id == 1 || data.id % this->resetIterations == 0) ? this->initialIterations : this->iterations;  // :92
     auto relaxedLabelImage = std::make_shared<image_t>(image.rows, image.cols, CV_16UC1);
     int maxLabelId = 0;
+    ScopedStream stream;
     {
-        FrameOrder::Turn turn(order, data.id);  // the reference's mutex (:97-99), taken in frame order
-        ScopedStream stream;
+        // The reference's mutex (:97-99), taken in frame order.  It covers the ENQUEUE only: cart_superpixels orders the
+        // calls on the device (event of the previous call), so the next frame's sweeps queue up right behind this frame's
+        // while this thread is still waiting for its own result -- the label state never leaves the GPU between frames.
+        FrameOrder::Turn turn(order, data.id);
         if (data.id % this->resetIterations == 0)  // :104-112
             if (cart_superpixels_reset(contourRelaxation, stream.s) != 0) engine->fail("cart_superpixels_reset");
         if (cart_superpixels_relax(contourRelaxation, image.ptr<uint8_t>(), image.step, image.type() == CV_8UC3 ? 3 : 1,
@@ -483,8 +486,8 @@ system_data_t SuperPixelModule::runInternal(System &, SystemRunData &data) {
                                    (int)numIterations, relaxedLabelImage->ptr<uint16_t>(), relaxedLabelImage->step, stream.s) != 0)
             engine->fail("cart_superpixels_relax");
         maxLabelId = cart_superpixels_max_label(contourRelaxation);
-        stream.wait();
     }
+    stream.wait();
     return MODULE_RETURN_ALL(std::make_pair(std::string(CARTSLAM_KEY_SUPERPIXELS), std::shared_ptr<void>(relaxedLabelImage)),
                              std::make_pair(std::string(CARTSLAM_KEY_SUPERPIXELS_MAX_LABEL), std::shared_ptr<void>(std::make_shared<contour::label_t>((contour::label_t)maxLabelId))));
 }
