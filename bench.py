@@ -32,6 +32,11 @@ def alg_bytes_aggregate(w, h, D, P):
     return w * h * (8 * P + P * D)
 
 
+def alg_bytes_wta(w, h, D, P):
+    """Winner-takes-all launch only: slab read (D B per pixel and path) + left disparity u16 + packed right view u16."""
+    return w * h * (P * D + 4)
+
+
 def cpu_baseline(w, h, D, P, seconds_budget=12.0):
     """Times the CPU oracle (the 'port': oracle/cart_oracle.c, OpenMP) on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -265,6 +270,18 @@ def main():
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
         }
+        wta_ms = stages.get("wta", 0.0)
+        if wta_ms > 0 and not fused:
+            # the second kernel of the path, same accounting (PD + 4 bytes per pixel), HBM-read bound
+            wta_bytes = alg_bytes_wta(w, h, D, P) * fpl
+            wt = None
+            try:
+                wt = json.load(open(tf)).get(f"wta_{w}x{h}_D{D}_P{P}_B{fpl}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                wt = None
+            out["roofline_wta"] = {"bound": "hbm", "kernel": "wta_kernel", "achieved": round(wta_bytes / (wta_ms * 1e-3) / 1e9, 1),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wta_bytes / (wta_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "traffic": wt, "alg_bytes_per_launch": wta_bytes, "launch_ms": round(wta_ms, 4)}
         if pcie:
             out["pcie_inclusive"] = pcie
         if seq:
