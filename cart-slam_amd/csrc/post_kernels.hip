@@ -413,98 +413,171 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void ccl_runs_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
-                                                       int w, int h, size_t npx) {
-    __shared__ int wave_tot[4];
-    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
-    int32_t *L = work + (size_t)frame * npx + (size_t)y * w;
-    int carry = -1;  // head of the run that continues from the previous 256-pixel chunk
-    for (int x0 = 0; x0 < w; x0 += 256) {
-        const int x = x0 + tid;
-        const int c = x < w ? row[x] : 255;
-        const int cp = (x > 0 && x < w) ? row[x - 1] : 254;
-        int s = (x < w && c != cp) ? x : -1;  // run head -> its own column
+// ---- tile-local labelling in LDS ------------------------------------------------------------------------------------
+// One workgroup labels a 64 x 32 tile completely in LDS: a wave owns 8 rows, a row's horizontal runs come from one
+// ballot (run head = nearest set bit at or below the lane), vertically touching runs are united with an atomicMin
+// union-find on an LDS parent array (only where a run starts above or below, like ccl_merge did), and every pixel
+// leaves with the GLOBAL linear index of its tile-local root.  Local indices r * 64 + x order like global ones inside the
+// tile, so the root is the component's smallest pixel of the tile.  What is left for global memory are the unions across
+// tile borders (ccl_border_kernel): ~1/25 of the unions of the run-based version, on trees one level deep.
+constexpr int CT_TW = 64, CT_TH = 32;
+
+__device__ __forceinline__ int lds_find(const int *P, int i) {
+    int p = P[i];
+    while (p != i) { i = p; p = P[i]; }
+    return i;
+}
+
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int w, int h, size_t npx) {
+    __shared__ uint8_t cls[CT_TH][CT_TW];
+    __shared__ int parent[CT_TH * CT_TW];
+    const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH, frame = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    // 1. classes + runs of the wave's rows
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {  // inclusive max-scan inside the wave
-            const int n = __shfl_up(s, o);
-            if (lane >= o) s = max(s, n);
-        }
-        if (lane == 63) wave_tot[wid] = s;
-        __syncthreads();
-        int prefix = carry, all = carry;
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int r = wid * (CT_TH / 4) + k, y = y0 + r;
+        const int c = (x < w && y < h) ? row_ptr(planes, pfs, pstep, frame, y)[x] : 255;
+        cls[r][lane] = (uint8_t)c;
+        const int left = __shfl_up(c, 1);
+        const bool valid = c <= 1;
+        const bool head = valid && (lane == 0 || left != c);
+        const unsigned long long heads = __ballot(head);
+        const int s = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));   // nearest head at or below the lane (exists when valid)
+        parent[r * CT_TW + lane] = valid ? r * CT_TW + s : -1;
+    }
+    __syncthreads();
+    // 2. unions of vertically touching runs, where a run starts in either row
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < wid) prefix = max(prefix, wave_tot[k]);
-            all = max(all, wave_tot[k]);
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int r = wid * (CT_TH / 4) + k;
+        if (r == 0) continue;
+        const int c = cls[r][lane];
+        if (c > 1 || cls[r - 1][lane] != c) continue;
+        const bool head = lane == 0 || cls[r][lane - 1] != c, up_head = lane == 0 || cls[r - 1][lane - 1] != c;
+        if (!head && !up_head) continue;
+        int a = parent[r * CT_TW + lane], b = parent[(r - 1) * CT_TW + lane];   // the two run heads
+        for (int guard = 0; guard < CT_TW * CT_TH; ++guard) {   // every retry strictly lowers a root
+            a = lds_find(parent, a); b = lds_find(parent, b);
+            if (a == b) break;
+            if (a < b) { const int t = a; a = b; b = t; }
+            const int old = atomicMin(&parent[a], b);
+            if (old == a) break;
+            a = old;
         }
-        s = max(s, prefix);
-        if (x < w) L[x] = c <= 1 ? y * w + s : -1;
-        carry = all;
-        __syncthreads();
+    }
+    __syncthreads();
+    // 3. pixel -> run head -> tile root, as a global index
+    int32_t *L = work + (size_t)frame * npx;
+#pragma unroll
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int r = wid * (CT_TH / 4) + k, y = y0 + r;
+        if (x >= w || y >= h) continue;
+        const int p = parent[r * CT_TW + lane];
+        int out = -1;
+        if (p >= 0) {
+            const int root = lds_find(parent, p);
+            out = (y0 + root / CT_TW) * w + x0 + (root % CT_TW);
+        }
+        L[y * w + x] = out;
     }
 }
 
-__global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
-                                                        int w, int h, size_t npx) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y + 1, frame = blockIdx.z;
-    if (x >= w || y >= h) return;
-    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y), *up = row_ptr(planes, pfs, pstep, frame, y - 1);
-    const uint8_t c = row[x];
-    if (c > 1 || up[x] != c) return;
-    const bool head = x == 0 || row[x - 1] != c, up_head = x == 0 || up[x - 1] != c;
-    if (!head && !up_head) return;  // this pair of runs is united at an earlier column
+// Unions across tile borders on the global parent array (a pixel points at its tile root, tile roots at themselves).
+// blockIdx.y < nby: the pixels of the rows y = 32 k against the row above; else the pixels of the columns x = 64 k against
+// the column to their left.  A pair is skipped when the pair before it along the border holds the same class on both
+// sides (that pair, plus the in-tile adjacency, already connects it) -- except on a tile's first row, where the "in-tile
+// adjacency" of a column pair would itself be a border pair that defers back to this one.
+__global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int w, int h, size_t npx,
+                                                         int nrows, int ncols) {
+    const int frame = blockIdx.z;
     int32_t *L = work + (size_t)frame * npx;
-    ccl_union(L, L[y * w + x], L[(y - 1) * w + x]);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.y < nrows) {   // horizontal border below row y - 1
+        const int y = ((int)blockIdx.y + 1) * CT_TH, x = t;
+        if (x >= w) return;
+        const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y), *up = row_ptr(planes, pfs, pstep, frame, y - 1);
+        const uint8_t c = row[x];
+        if (c > 1 || up[x] != c) return;
+        if (x > 0 && row[x - 1] == c && up[x - 1] == c) return;
+        ccl_union(L, L[y * w + x], L[(y - 1) * w + x]);
+    } else {                          // vertical border left of column x
+        const int x = ((int)blockIdx.y - nrows + 1) * CT_TW, y = t;
+        if (y >= h) return;
+        const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
+        const uint8_t c = row[x];
+        if (c > 1 || row[x - 1] != c) return;
+        if (y % CT_TH != 0) {
+            const uint8_t *up = row_ptr(planes, pfs, pstep, frame, y - 1);
+            if (up[x] == c && up[x - 1] == c) return;
+        }
+        ccl_union(L, L[y * w + x], L[y * w + x - 1]);
+    }
+    (void)ncols;
 }
 
-__global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work,
-                                                           int32_t *ncomp, int w, int h, size_t npx) {
+// Tile roots (pixels that point at themselves after ccl_tile_kernel, possibly re-linked by a border union) resolve their
+// root once, so that ccl_final_kernel reads two links per pixel instead of walking the chain of tile roots.  Writing a
+// root into a link keeps the forest valid whatever other threads read meanwhile.
+__global__ __launch_bounds__(256) void ccl_compress_kernel(int32_t *work, int w, int h, size_t npx) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= w || y >= h) return;
-    const uint8_t *row = row_ptr(planes, pfs, pstep, frame, y);
-    const uint8_t c = row[x];
-    if (c > 1 || (x > 0 && row[x - 1] == c)) return;  // only run heads carry links that others follow
     int32_t *L = work + (size_t)frame * npx;
     const int i = y * w + x;
-    const int p = L[i];
-    if (p == i) {  // a root: nothing links it further, nobody rewrites it in this pass
-        if (ncomp) atomicAdd(&ncomp[frame], 1);
-        return;
-    }
+    const int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p < 0 || p == i) return;                 // unlabelled, or a root
+    // only tile roots carry links that others follow: a non-root pixel points at its tile root q with q's tile = its own
+    const int ty = y / CT_TH, tx = x / CT_TW;
+    const int py = p / w, px = p - py * w;
+    if (py / CT_TH == ty && px / CT_TW == tx) return;   // link inside the tile: an ordinary pixel (tile roots link outwards or to themselves)
     int r = p;
     int q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q == r) return;  // already links straight to a root
+    if (q == r) return;
     while (q != r) { r = q; q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    // writing the root into a link keeps the forest valid whatever other threads read meanwhile
     __hip_atomic_store(&L[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int w,
+__global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int32_t *ncomp, int w,
                                                         int h, size_t npx) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
-    if (x >= w || y >= h) return;
-    const int32_t *L = work + (size_t)frame * npx;
-    int r = L[y * w + x];
-    if (r >= 0) {
-        int q = L[r];
-        while (q != r) { r = q; q = L[r]; }  // pixel -> run head -> root after ccl_compress
+    bool is_root = false;
+    if (x < w && y < h) {
+        const int32_t *L = work + (size_t)frame * npx;
+        int r = L[y * w + x];
+        if (r >= 0) {
+            int q = L[r];
+            while (q != r) { r = q; q = L[r]; }  // pixel -> tile root -> root
+            is_root = r == y * w + x;
+        }
+        row_ptr(ids, ifs, istep, frame, y)[x] = r;
     }
-    row_ptr(ids, ifs, istep, frame, y)[x] = r;
+    if (ncomp) {   // components = pixels that are their own root; one global atomic per workgroup (noise scenes have ~10^4 roots per frame,
+                   // and that many same-address atomics took longer than the labelling)
+        __shared__ int roots;
+        if (threadIdx.x == 0 && threadIdx.y == 0) roots = 0;
+        __syncthreads();
+        const unsigned long long m = __ballot(is_root);
+        if (threadIdx.x == 0 && m) atomicAdd(&roots, __popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0 && roots) atomicAdd(&ncomp[frame], roots);
+    }
 }
 
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
                 int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
     const size_t npx = (size_t)w * h;
-    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
     if (ncomp) (void)hipMemsetAsync(ncomp, 0, sizeof(int32_t) * (size_t)n_frames, s);
-    hipLaunchKernelGGL(ccl_runs_kernel, dim3(h, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx);
-    if (h > 1) {
-        dim3 mgrid((w + 63) / 64, (h - 1 + 3) / 4, n_frames);
-        hipLaunchKernelGGL(ccl_merge_kernel, mgrid, block, 0, s, planes, pstep, pfs, work, w, h, npx);
+    const int ntx = (w + CT_TW - 1) / CT_TW, nty = (h + CT_TH - 1) / CT_TH;
+    hipLaunchKernelGGL(ccl_tile_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx);
+    const int nrows = nty - 1, ncols = ntx - 1;   // inner tile borders
+    if (nrows + ncols > 0) {
+        const int span = std::max(nrows > 0 ? w : 0, ncols > 0 ? h : 0);
+        hipLaunchKernelGGL(ccl_border_kernel, dim3((span + 255) / 256, nrows + ncols, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx, nrows, ncols);
     }
-    hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, planes, pstep, pfs, work, ncomp, w, h, npx);
-    hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, w, h, npx);
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
+    if (nrows + ncols > 0) hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, work, w, h, npx);
+    hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, w, h, npx);
 }
 
 // ------------------------------------------------------------------ component table (oracle S12: id, label, area, bbox)

@@ -734,3 +734,34 @@ def test_plane_multi_equals_batch():
         assert torch.equal(got_d[f], want_d[f]) and torch.equal(got_p[f], want_p[f]), f
     one = eng.plane_label_multi([D[3]], torch.zeros(256, dtype=torch.int32, device="cuda"), params[3])
     assert torch.equal(one[1][0], want_p[3])
+
+
+@pytest.mark.gpu
+def test_ccl_tile_borders(torch_cuda):
+    """The labelling works on 64 x 32 tiles in LDS and unites across tile borders afterwards: sizes around the tile
+    multiples, blobs at several scales (components that span many tiles and noise that does not), and U shapes whose two
+    arms lie in one tile and meet only in the neighbouring tile (two tile roots of ONE tile end up in one component)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    for w, h in [(64, 32), (65, 33), (63, 31), (128, 64), (129, 65), (200, 100), (16, 8), (320, 37), (70, 160)]:
+        eng = make_engine(w, h, 0, 0, inflight=6)
+        yy, xx = np.mgrid[0:h, 0:w]
+        maps = [rng.integers(0, 3, (h, w)).astype(np.uint8)]
+        for scale in (3, 9, 27):
+            maps.append(np.kron(rng.integers(0, 3, (h // scale + 1, w // scale + 1)), np.ones((scale, scale), int))[:h, :w].astype(np.uint8))
+        u = np.full((h, w), 2, np.uint8)   # U across the first vertical tile border: arms on rows 2 and 6 left of x = 64, joined at x >= 64
+        if w > 70 and h > 8:
+            u[2, 40:70] = 0; u[6, 40:70] = 0; u[2:7, 69] = 0
+            u[10:12, :] = 1
+        maps.append(u)
+        v = np.full((h, w), 2, np.uint8)   # the same across the first horizontal border (y = 32), plus a frame around the image
+        if h > 40 and w > 8:
+            v[20:40, 3] = 1; v[20:40, 7] = 1; v[39, 3:8] = 1
+        v[0, :] = 0; v[-1, :] = 0; v[:, 0] = 0; v[:, -1] = 0
+        maps.append(v)
+        ids, n = eng.plane_ccl(dev(torch, np.stack(maps)))
+        ids, n = ids.cpu().numpy(), n.cpu().numpy()
+        for f, m in enumerate(maps):
+            e, en = O.ccl(m)
+            assert (ids[f] == e).all() and n[f] == en, f"{w}x{h} map {f}"
+        eng.close()
