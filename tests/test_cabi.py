@@ -73,3 +73,21 @@ def test_host_peak_finder_matches_oracle():
         ok, p = find_plane_params(hh, prev)
         eok, ep = O.histogram_peak_params(hh, prev)
         assert ok == eok and p.as_tuple() == ep
+
+
+def test_every_entry_point_rejects_null_arguments():
+    """No entry point dereferences a NULL handle / image / table: all-zero arguments give a non-zero status and a message
+    (the reference's GPU failures exit() the process, include/utils/cuda.cuh:193-201; the C ABI never does).  Runs
+    without a GPU: validation comes before any device call."""
+    from cartslam import _lib
+    lib = _lib.load()
+    skipped = {"cart_engine_create", "cart_find_plane_params", "cart_find_peaks"}   # covered by their own tests
+    checked = 0
+    for name, (res, args) in _lib.PROTOTYPES.items():
+        if res is not C.c_int or not args or name in skipped:
+            continue
+        zeros = [a(0) if a in (C.c_int, C.c_size_t, C.c_float, C.c_double) else None for a in args]
+        assert getattr(lib, name)(*zeros) != 0, name
+        assert lib.cart_last_error(None), name
+        checked += 1
+    assert checked >= 25
