@@ -517,50 +517,62 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t *planes, 
     (void)ncols;
 }
 
-// Tile roots (pixels that point at themselves after ccl_tile_kernel, possibly re-linked by a border union) resolve their
-// root once, so that ccl_final_kernel reads two links per pixel instead of walking the chain of tile roots.  Writing a
-// root into a link keeps the forest valid whatever other threads read meanwhile.
-__global__ __launch_bounds__(256) void ccl_compress_kernel(int32_t *work, int w, int h, size_t npx) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
-    if (x >= w || y >= h) return;
-    int32_t *L = work + (size_t)frame * npx;
-    const int i = y * w + x;
-    const int p = __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p < 0 || p == i) return;                 // unlabelled, or a root
-    // only tile roots carry links that others follow: a non-root pixel points at its tile root q with q's tile = its own
-    const int ty = y / CT_TH, tx = x / CT_TW;
-    const int py = p / w, px = p - py * w;
-    if (py / CT_TH == ty && px / CT_TW == tx) return;   // link inside the tile: an ordinary pixel (tile roots link outwards or to themselves)
-    int r = p;
-    int q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q == r) return;
-    while (q != r) { r = q; q = __hip_atomic_load(&L[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __hip_atomic_store(&L[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
+// Final ids, again one workgroup per 64 x 32 tile.  After the border unions a pixel's link is either inside its tile (an
+// ordinary pixel pointing at its tile root, or a tile root that a union hung under another root of the same tile) or it
+// is a tile root: a link to itself or to a root outside the tile.  Tile roots walk the global forest once and park the
+// result in LDS; everybody else follows its in-tile links through an LDS copy of the tile's links until it meets a
+// resolved entry (one or two hops).  No per-pixel gathers from global memory, no separate compression pass.
 __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int32_t *ncomp, int w,
                                                         int h, size_t npx) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
-    bool is_root = false;
-    if (x < w && y < h) {
-        const int32_t *L = work + (size_t)frame * npx;
-        int r = L[y * w + x];
-        if (r >= 0) {
-            int q = L[r];
-            while (q != r) { r = q; q = L[r]; }  // pixel -> tile root -> root
-            is_root = r == y * w + x;
+    __shared__ int link[CT_TH * CT_TW];      // local index of the pixel's link target, -1 unlabelled, -2 resolved in root_of
+    __shared__ int root_of[CT_TH * CT_TW];
+    __shared__ int roots;
+    const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH, frame = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    const int32_t *L = work + (size_t)frame * npx;
+    if (threadIdx.x == 0) roots = 0;
+#pragma unroll
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;
+        int lk = -1, ro = -1;
+        if (x < w && y < h) {
+            const int gi = y * w + x;
+            const int t = L[gi];
+            if (t >= 0) {
+                const int ty = t / w, tx = t - ty * w;
+                const bool inside = ty >= y0 && ty < y0 + CT_TH && tx >= x0 && tx < x0 + CT_TW;
+                if (inside && t != gi) {
+                    lk = (ty - y0) * CT_TW + (tx - x0);
+                } else {   // a tile root: resolve it in the global forest
+                    int q = t, n = L[q];
+                    while (n != q) { q = n; n = L[q]; }
+                    lk = -2; ro = q;
+                }
+            }
         }
-        row_ptr(ids, ifs, istep, frame, y)[x] = r;
+        link[li] = lk; root_of[li] = ro;
     }
-    if (ncomp) {   // components = pixels that are their own root; one global atomic per workgroup (noise scenes have ~10^4 roots per frame,
-                   // and that many same-address atomics took longer than the labelling)
-        __shared__ int roots;
-        if (threadIdx.x == 0 && threadIdx.y == 0) roots = 0;
+    __syncthreads();
+    int found = 0;
+#pragma unroll
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;
+        if (x >= w || y >= h) continue;
+        int id = -1;
+        int cur = li, lk = link[li];
+        if (lk != -1) {
+            while (lk >= 0) { cur = lk; lk = link[cur]; }   // in-tile links only ever lead to smaller indices: terminates at a resolved entry
+            id = root_of[cur];
+        }
+        row_ptr(ids, ifs, istep, frame, y)[x] = id;
+        found += id == y * w + x;
+    }
+    if (ncomp) {   // components = pixels that are their own root; one global atomic per workgroup (noise scenes have ~10^4 roots per
+                   // frame, and that many same-address atomics took longer than the labelling)
+        if (found) atomicAdd(&roots, found);
         __syncthreads();
-        const unsigned long long m = __ballot(is_root);
-        if (threadIdx.x == 0 && m) atomicAdd(&roots, __popcll(m));
-        __syncthreads();
-        if (threadIdx.x == 0 && threadIdx.y == 0 && roots) atomicAdd(&ncomp[frame], roots);
+        if (threadIdx.x == 0 && roots) atomicAdd(&ncomp[frame], roots);
     }
 }
 
@@ -575,9 +587,7 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
         const int span = std::max(nrows > 0 ? w : 0, ncols > 0 ? h : 0);
         hipLaunchKernelGGL(ccl_border_kernel, dim3((span + 255) / 256, nrows + ncols, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx, nrows, ncols);
     }
-    dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames), block(64, 4);
-    if (nrows + ncols > 0) hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, s, work, w, h, npx);
-    hipLaunchKernelGGL(ccl_final_kernel, grid, block, 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, w, h, npx);
+    hipLaunchKernelGGL(ccl_final_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, w, h, npx);
 }
 
 // ------------------------------------------------------------------ component table (oracle S12: id, label, area, bbox)
@@ -724,6 +734,6 @@ void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int
                        (const int32_t *)slot, table, max_components, w, h, npx);
 }
 
-int kernel_count() { return 43; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 17 + superpixel_kernels 8 + flow 3
+int kernel_count() { return 42; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 16 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd
