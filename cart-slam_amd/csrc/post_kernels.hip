@@ -382,12 +382,13 @@ void launch_plane_schedule(ScheduleState *state, int provider, int first_id, int
                        hists, params_out);
 }
 
-// ------------------------------------------------------------------ connected components (run-based union-find)
-// 1. ccl_runs:    every pixel links to the first pixel of its horizontal run (block scan per row),
-// 2. ccl_merge:   one union per pair of vertically touching runs (only where a run starts above or
-//                 below), atomicMin-based so roots are the minimal linear index (oracle S12),
-// 3. ccl_compress: run heads resolve their root, 4. ccl_final: every pixel reads root-of-run-head.
-// Parent links only ever decrease (atomicMin) and always point inside the component, so a stale
+// ------------------------------------------------------------------ connected components (tile-local + border union-find)
+// 1. ccl_tile:   a workgroup labels a 64 x 32 tile in LDS (runs by ballot, LDS union-find) -> every pixel links to its
+//                tile root, by global index;
+// 2. ccl_border: one union per run that touches a tile border, atomicMin-based on the global link array, so roots are
+//                the minimal linear index of the component (oracle S12);
+// 3. ccl_final:  tile roots resolve their root once (LDS), every other pixel follows its in-tile link.
+// Global parent links only ever decrease (atomicMin) and always point inside the component, so a stale
 // read (per-XCD L2s are not coherent inside a launch) can only lengthen a walk, never break it;
 // later passes run in later launches and therefore see every link.
 // find with path halving: every visited node is re-linked to its grandparent.  A link only ever moves to a smaller index
@@ -416,7 +417,7 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
 // ---- tile-local labelling in LDS ------------------------------------------------------------------------------------
 // One workgroup labels a 64 x 32 tile completely in LDS: a wave owns 8 rows, a row's horizontal runs come from one
 // ballot (run head = nearest set bit at or below the lane), vertically touching runs are united with an atomicMin
-// union-find on an LDS parent array (only where a run starts above or below, like ccl_merge did), and every pixel
+// union-find on an LDS parent array (only where a run starts above or below), and every pixel
 // leaves with the GLOBAL linear index of its tile-local root.  Local indices r * 64 + x order like global ones inside the
 // tile, so the root is the component's smallest pixel of the tile.  What is left for global memory are the unions across
 // tile borders (ccl_border_kernel): ~1/25 of the unions of the run-based version, on trees one level deep.
