@@ -765,3 +765,20 @@ def test_ccl_tile_borders(torch_cuda):
             e, en = O.ccl(m)
             assert (ids[f] == e).all() and n[f] == en, f"{w}x{h} map {f}"
         eng.close()
+
+
+@pytest.mark.gpu
+def test_full_size_oracle_1080p_d256(torch_cuda):
+    """BASELINE configs[3] against the oracle on the full image: 1920x1080, D=256, 8 paths, a batch of 4 (fused WTA, the
+    default there) and a single pair (two-kernel WTA), bit for bit; ~2 s of oracle time per pair on the GPU box's cores."""
+    torch = torch_cuda
+    w, h, D, P = 1920, 1080, 256, 8
+    ls, rs = synth.make_batch(2, w, h, D, 4)
+    want = [O.disparity_module(ls[k], rs[k], D, P, 4, radius=2, iterations=1) for k in range(2)]
+    eng = make_engine(w, h, D, P, radius=2, iters=1, inflight=4)
+    L, R = dev(torch, np.concatenate([ls, ls])), dev(torch, np.concatenate([rs, rs]))
+    got = eng.compute_disparity(L, R).cpu().numpy()
+    for k in range(4):
+        assert (got[k] == want[k % 2]).all(), f"batch frame {k}: {int((got[k] != want[k % 2]).sum())} pixels differ"
+    assert (eng.compute_disparity(L[1], R[1]).cpu().numpy() == want[1]).all(), "single pair"
+    eng.close()
