@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src,
                                                              int min_disp16, int max_disp) {
     const int xb = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (xb >= w || y >= h) return;
+    // vector accesses need 4-byte aligned source rows / 8-byte aligned destination rows (the engine's own buffers are)
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | src_step | src_fs) & 3) == 0;
+    const bool vec_out = ((reinterpret_cast<uintptr_t>(out_row(dst, frame, 0)) | dst.step) & 7) == 0;
     int csum[6], ccnt[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) { csum[c] = 0; ccnt[c] = 0; }
@@ -66,21 +69,37 @@ __global__ __launch_bounds__(256) void interpolate_r2_kernel(const int16_t *src,
         const int yy = y + l;
         if (yy < 0 || yy >= h) continue;
         const int16_t *row = row_ptr(src, src_fs, src_step, frame, yy);
+        int v[6];
+        if (vec && xb >= 2 && xb + 6 <= w) {
+            // pixels xb-2 .. xb+5 as one 16-byte load (4-byte aligned: rows and xb are), the window is its middle six
+            typedef uint32_t v4u_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const v4u_a4 q = *reinterpret_cast<const v4u_a4 *>(row + xb - 2);
+            v[0] = (int)q.x >> 16; v[1] = (int16_t)q.y; v[2] = (int)q.y >> 16; v[3] = (int16_t)q.z; v[4] = (int)q.z >> 16; v[5] = (int16_t)q.w;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int xx = xb - 1 + c;
-            if (xx < 0 || xx >= w) continue;
-            const int v = row[xx];
-            if (v > min_disp16 && v < max_disp) { csum[c] += v; ++ccnt[c]; }
+            for (int c = 0; c < 6; ++c) {
+                const int xx = xb - 1 + c;
+                v[c] = (xx >= 0 && xx < w) ? (int)row[xx] : (int)0x80000000;   // never passes the range test below (min_disp16 > -2^20)
+            }
         }
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (v[c] > min_disp16 && v[c] < max_disp) { csum[c] += v[c]; ++ccnt[c]; }
     }
     int16_t *orow = out_row(dst, frame, y);
+    int16_t o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (xb + i >= w) break;
         const int sum = csum[i] + csum[i + 1] + csum[i + 2], count = ccnt[i] + ccnt[i + 1] + ccnt[i + 2];
         // interpolation.cu:33: count > r*r + 1 = 5
-        orow[xb + i] = count > 5 ? (int16_t)(int)((float)sum / (float)count) : (int16_t)INVALID;
+        o[i] = count > 5 ? (int16_t)(int)((float)sum / (float)count) : (int16_t)INVALID;
+    }
+    if (vec_out && xb + 4 <= w) {
+        *reinterpret_cast<uint2 *>(orow + xb) = make_uint2((uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (xb + i < w) orow[xb + i] = o[i];
     }
 }
 
