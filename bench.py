@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- stereo-pairs/sec of the dense-stereo hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL: either under `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as the plain command above, in which case this
+process starts those N ranks itself (before it touches a GPU) and relays rank 0's JSON line and the exit code.
 
 One "step" = one pass of the whole hot path (disparity module: census -> 8-path SGM -> WTA ->
 medians/LR/range -> interpolate; plane module: vertical derivative + histogram -> plane parameters
@@ -82,6 +86,28 @@ def cpu_baseline(w, h, D, P, seconds_budget=12.0):
     return out
 
 
+def launch_ranks(args):
+    """Plain `python bench.py --gpus N` (no RANK in the environment): start N fresh rank processes through
+    torch.distributed.run and relay their output.  Nothing in this process has initialised a GPU
+    (torch.cuda.device_count() does not), so the children start from a clean state."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.allow_shared_gpu:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this box has {have} "
+                         "(--allow-shared-gpu stacks ranks on the GPUs there are: rehearsals only, never a scaling number)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +124,11 @@ def main():
     ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--allow-shared-gpu", action="store_true", help="rehearsals only: let ranks share a GPU when the box has fewer than --gpus")
+    ap.add_argument("--plan", default="auto", choices=["auto", "slabs", "fused_up", "pairs"], help="force a launch plan of the SGM core (all bit-identical)")
     args = ap.parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     import numpy as np
     import torch
@@ -110,11 +140,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: one rank per GPU, the two must agree")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
         sys.exit("bench.py needs a GPU (no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node; lets 2 ranks rehearse on 1 GPU
+    if local_rank >= ndev and not args.allow_shared_gpu:
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own ({ndev} visible); "
+                 "--allow-shared-gpu is for rehearsals only")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -126,6 +159,9 @@ def main():
     w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
                  max_inflight=B if args.no_overlap else 2 * B, device_id=dev_index)
+    if args.plan != "auto":
+        eng.set_plan(args.plan)
+    plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
     pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=not args.no_overlap)
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     n_distinct = min(B, 4)
@@ -234,19 +270,17 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
-        fpl = min(B, 16)  # frames per launch: the engine runs batches as sub-batches of <= 16 frames (cart_engine.hip)
+        fpl = plan["frames_per_launch"]  # the engine runs batches as sub-batches (cart_engine_describe_plan)
         agg_ms = stages.get("aggregate", 0.0)  # mean duration of ONE aggregate launch (fpl frames)
-        # D=256 batches run the WTA fused with the "up" direction (cart_engine.hip): the aggregate launch then covers P-1 paths
-        nblk16 = (w + 15) // 16
-        fused = D >= 256 and fpl >= max(2, (448 + nblk16 - 1) // nblk16) and os.environ.get("CART_FUSED_WTA", "1") != "0"
-        agg_bytes = alg_bytes_aggregate(w, h, D, P - 1 if fused else P) * fpl
+        fused = plan["plan"] != "slabs"        # the WTA sweep computes paths on the fly: the aggregate launch covers fewer
+        agg_bytes = alg_bytes_aggregate(w, h, D, plan["slabs_written"]) * fpl
         achieved = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                key = f"aggregate_{w}x{h}_D{D}_P{P}_B{fpl}"
+                key = f"aggregate_{w}x{h}_D{D}_P{P}_B{fpl}" + ("" if plan["plan"] == "slabs" else "_" + plan["plan"])
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -258,7 +292,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{w}x{h} gray stereo, D={D}, {P}-direction SGM + interpolate(r=2,it=1) + plane "
                                    f"labelling (histogram_peak) + CCL; BASELINE.json configs[2]",
-                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}"},
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}",
+                       "launch_plan": plan,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": "aggregate_kernel (all paths of all frames in one launch)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

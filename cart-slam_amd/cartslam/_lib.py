@@ -27,6 +27,15 @@ class PlaneParams(C.Structure):
         return tuple(getattr(self, n) for n, _ in self._fields_)
 
 
+class LaunchPlan(C.Structure):
+    # mirrors cart_launch_plan (include/cart_engine.h)
+    _fields_ = [("frames_per_launch", C.c_int), ("plan", C.c_int), ("slabs_written", C.c_int)]
+
+
+PLAN_AUTO, PLAN_SLABS, PLAN_FUSED_UP, PLAN_PAIRS = -1, 0, 1, 2      # CART_PLAN_*
+OPT_PLAN, OPT_PLAN_MIN_FRAMES, OPT_CHUNK_FRAMES = 0, 1, 2           # CART_OPT_*
+
+
 class SuperpixelParams(C.Structure):
     # mirrors cart_superpixel_params (include/cart_engine.h; reference cartconfig.cpp:121-133)
     _fields_ = [(n, C.c_double) for n in (
@@ -41,6 +50,9 @@ PROTOTYPES = {
     "cart_engine_create": (_i, [C.POINTER(EngineParams), C.POINTER(_vp)]),
     "cart_engine_destroy": (None, [_vp]),
     "cart_last_error": (C.c_char_p, [_vp]),
+    "cart_engine_set_option": (_i, [_vp, _i, _i]),
+    "cart_engine_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
+    "cart_engine_describe_plan": (_i, [_vp, _i, C.POINTER(LaunchPlan)]),
     "cart_compute_disparity": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
     "cart_compute_disparity_batch": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp]),
     "cart_compute_disparity_multi": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
@@ -72,6 +84,7 @@ PROTOTYPES = {
     "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),
+    "cart_debug_uniq_table": (_i, [_vp, _i, C.POINTER(C.c_uint16)]),
     "cart_engine_set_timing": (_i, [_vp, _i]),
     "cart_engine_collect_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cart_engine_version": (C.c_char_p, []),

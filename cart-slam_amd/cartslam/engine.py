@@ -77,6 +77,23 @@ class Engine:
         if rc != 0:
             raise EngineError(f"{what}: " + self._lib.cart_last_error(self._h).decode())
 
+    # ---- launch plan (every plan gives the same bits; include/cart_engine.h CART_PLAN_*) ----
+    def set_plan(self, plan, min_frames=1):
+        """plan: "auto" | "slabs" | "fused_up" | "pairs"; a forced plan applies to launches of >= min_frames frames."""
+        code = {"auto": _lib.PLAN_AUTO, "slabs": _lib.PLAN_SLABS, "fused_up": _lib.PLAN_FUSED_UP, "pairs": _lib.PLAN_PAIRS}[plan]
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN, code), "cart_engine_set_option")
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN_MIN_FRAMES, int(min_frames)), "cart_engine_set_option")
+
+    def set_chunk_frames(self, n):
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_CHUNK_FRAMES, int(n)), "cart_engine_set_option")
+
+    def describe_plan(self, n_frames):
+        """-> dict(frames_per_launch, plan, slabs_written) of a batched call of n_frames."""
+        lp = _lib.LaunchPlan()
+        self._check(self._lib.cart_engine_describe_plan(self._h, int(n_frames), C.byref(lp)), "cart_engine_describe_plan")
+        return {"frames_per_launch": lp.frames_per_launch, "plan": {0: "slabs", 1: "fused_up", 2: "pairs"}[lp.plan],
+                "slabs_written": lp.slabs_written}
+
     # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
     def compute_disparity(self, left, right, out=None):
         import torch
@@ -433,6 +450,17 @@ class Superpixels:
             self.close()
         except Exception:
             pass
+
+
+def uniq_table(uniqueness_ratio, engine=None):
+    """Integer uniqueness thresholds T(best) for best = 0..2047 (cart_debug_uniq_table): from the GPU when an engine is
+    given, from the host-compiled copy of the same function otherwise."""
+    lib = _lib.load()
+    out = np.empty(2048, np.uint16)
+    rc = lib.cart_debug_uniq_table(engine._h if engine is not None else None, int(uniqueness_ratio), out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    if rc != 0:
+        raise EngineError("cart_debug_uniq_table: " + lib.cart_last_error(None).decode())
+    return out
 
 
 def find_plane_params(hist256, params=None):

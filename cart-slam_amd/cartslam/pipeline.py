@@ -102,13 +102,14 @@ class StereoPipeline:
     (PlaneParameterSchedule + cart_find_plane_params), which is what the reference's module does per frame."""
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
-                 with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096):
+                 with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096, keep_hists=False):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
         self.schedule = PlaneParameterSchedule(provider, static_params, update_interval, reset_interval)
         self.dev_schedule = DevicePlaneSchedule(engine, provider, static_params, update_interval, reset_interval) if device_schedule else None
         self.with_ccl = with_ccl
+        self.keep_hists = keep_hists           # out["hists"]: a copy of this rank's per-frame 256-bin histograms (tests)
         self.max_components = max_components   # rows of the per-frame component table (id, label, area, bbox)
         self.group = group
         self.world = 1
@@ -169,6 +170,7 @@ class StereoPipeline:
             self._hist = torch.empty((n, 256), dtype=torch.int32, device=left.device)
         self._hist.zero_()
         deriv = eng.plane_derivative_hist(disp, self._hist, per_frame_hist=True)
+        kept = self._hist.clone() if self.keep_hists else None
         if self.dev_schedule is not None:
             hists = self._hist
             if self.world > 1 and self.schedule.provider != "static":
@@ -184,6 +186,8 @@ class StereoPipeline:
             self.next_id += n * self.world
             planes = eng.plane_classify_dev(deriv, mine)
             out = dict(disparity=disp, planes=planes, params=mine)
+            if kept is not None:
+                out["hists"] = kept
             if self.with_ccl:
                 out["ids"], out["n_components"] = eng.plane_ccl(planes)
                 out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
@@ -206,6 +210,8 @@ class StereoPipeline:
         self.next_id += n * self.world
         planes = eng.plane_classify(deriv, list(per_frame) if n > 1 else per_frame[0])
         out = dict(disparity=disp, planes=planes, params=per_frame)
+        if kept is not None:
+            out["hists"] = kept
         if self.with_ccl:
             out["ids"], out["n_components"] = eng.plane_ccl(planes)
             out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)

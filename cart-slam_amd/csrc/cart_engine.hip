@@ -72,7 +72,9 @@ struct cart_engine {
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
-    int fused_min_frames = 1 << 30; // batches of at least this many frames take the fused WTA
+    int auto_fused_min_frames = 1 << 30; // CART_OPT_PLAN = auto: launches of at least this many frames take the fused WTA
+    int opt_plan = CART_PLAN_AUTO;       // cart_engine_set_option
+    int opt_plan_min_frames = 1;         // with a forced plan: launches of fewer frames still take CART_PLAN_SLABS
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
@@ -131,7 +133,14 @@ int acquire(cart_engine *e, int n, hipStream_t stream, Lease *out) {
         Slot &s = e->slots[s0 + k];
         if (s.used && s.last_stream != stream && s.owner != waited) {
             hipError_t err = hipStreamWaitEvent(stream, e->slots[s.owner].done, 0);
-            if (err != hipSuccess) return fail(std::string("hipStreamWaitEvent: ") + hipGetErrorString(err));
+            if (err != hipSuccess) {   // hand the slots back: later callers must not wait for a lease that never existed
+                {
+                    std::lock_guard<std::mutex> relk(e->mu);
+                    for (int j = 0; j < n; ++j) e->slots[s0 + j].busy = false;
+                }
+                e->cv.notify_all();
+                return fail(std::string("hipStreamWaitEvent: ") + hipGetErrorString(err));
+            }
             waited = s.owner;
         }
     }
@@ -163,10 +172,10 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     // start first; slab index `path` keeps the oracle's order {down, up, right, left, diagonals}.
     struct D { int dx, dy, path; };
     static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
-    // diagnostic only (timing experiments; results are wrong when directions are dropped):
-    // CART_DEBUG_DIRMASK = bit mask over the launch-order directions to keep
     unsigned mask = keep;
+#ifdef CART_EXPERIMENTS   // timing experiments only (results are wrong when directions are dropped); never in a product build
     if (const char *m = std::getenv("CART_DEBUG_DIRMASK")) mask &= (unsigned)std::strtoul(m, nullptr, 0);
+#endif
     int blk = 0, nd = 0;
     const int lpb = agg_lines_per_block(g.D);
     for (int i = 0; i < g.P; ++i) {
@@ -182,6 +191,12 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     a.ndirs = nd;
     a.blocks_per_frame = blk;
     a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
+}
+
+// The launch plan of `n` frames handed to one launch sequence (include/cart_engine.h, CART_PLAN_*).
+int plan_for(const cart_engine *e, int n) {
+    if (e->opt_plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
+    return n >= e->opt_plan_min_frames ? e->opt_plan : CART_PLAN_SLABS;
 }
 
 int validate(const cart_engine_params *p) {
@@ -291,21 +306,19 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     // Fused WTA (the "up" direction computed inside the WTA sweep, 1/P less slab traffic): measured on MI355X at
     // 1242x375, batch 16 (profiles/tools/disparity_only.py): D=256 -9 % (4 paths) / -15 % (8 paths) per batch, D=128
     // even, D=64 +4..6 %; D=256 batches of 4 frames: +5 % at 1242x375, -11 % at 1920x1080 -- so it is the default for
-    // D=256 batches that give the sweep enough workgroups.  CART_FUSED_WTA=1 forces it for every D (from
-    // 8 frames up), =0 disables it; CART_FUSED_MIN_FRAMES overrides the batch size from which it is used.
+    // D=256 batches that give the sweep enough workgroups.  Every plan gives the same bits; cart_engine_set_option
+    // overrides the choice (tests and measurements), nothing is read from the environment.
     {   // from ~450 workgroups (16 columns each at D=256) the sweep fills the chip: 6 frames at 1242 px, 4 at 1920 px
         const int nblk = (g.w + 15) / 16;
-        e->fused_min_frames = g.D >= 256 ? std::max(2, (448 + nblk - 1) / nblk) : 1 << 30;
+        e->auto_fused_min_frames = g.D >= 256 ? std::max(2, (448 + nblk - 1) / nblk) : 1 << 30;
     }
-    if (const char *f = std::getenv("CART_FUSED_WTA")) e->fused_min_frames = std::atoi(f) == 0 ? 1 << 30 : std::min(e->fused_min_frames, 8);
-    if (const char *f = std::getenv("CART_FUSED_MIN_FRAMES")) e->fused_min_frames = std::max(1, std::atoi(f));
-    if (const char *f = std::getenv("CART_CHUNK_FRAMES")) e->chunk_frames = std::max(1, std::atoi(f));  // experiments: frames per launch sequence (strided batches only)
     *out = e;
     return 0;
 }
 
 void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
+    (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
     void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws};
     for (void *b : bufs)
@@ -324,6 +337,48 @@ const char *cart_engine_version(void) {
     static char buf[64];
     std::snprintf(buf, sizeof(buf), "cart_engine gfx950 %d kernels", kernel_count());
     return buf;
+}
+
+int cart_engine_set_option(cart_engine *e, int option, int value) {
+    if (!e) return fail("engine is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    switch (option) {
+        case CART_OPT_PLAN:
+            if (value < CART_PLAN_AUTO || value > CART_PLAN_PAIRS) return fail("unknown plan");
+            e->opt_plan = value;
+            return 0;
+        case CART_OPT_PLAN_MIN_FRAMES:
+            if (value < 1) return fail("min frames must be >= 1");
+            e->opt_plan_min_frames = value;
+            return 0;
+        case CART_OPT_CHUNK_FRAMES:
+            if (value < 1 || value > 64) return fail("chunk frames must be in [1, 64]");  // pointer-table (multi) calls stay at kLaunchFrames
+            e->chunk_frames = value;
+            return 0;
+        default: return fail("unknown option");
+    }
+}
+
+int cart_engine_get_option(cart_engine *e, int option, int *value) {
+    if (!e || !value) return fail("bad arguments");
+    std::lock_guard<std::mutex> lk(e->mu);
+    switch (option) {
+        case CART_OPT_PLAN: *value = e->opt_plan; return 0;
+        case CART_OPT_PLAN_MIN_FRAMES: *value = e->opt_plan_min_frames; return 0;
+        case CART_OPT_CHUNK_FRAMES: *value = e->chunk_frames; return 0;
+        default: return fail("unknown option");
+    }
+}
+
+int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *out) {
+    if (!e || !out) return fail("bad arguments");
+    if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
+    if (n_frames < 1) return fail("n_frames must be positive");
+    std::lock_guard<std::mutex> lk(e->mu);
+    out->frames_per_launch = std::min(n_frames, e->chunk_frames);
+    out->plan = plan_for(e, out->frames_per_launch);
+    out->slabs_written = out->plan == CART_PLAN_PAIRS ? 5 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
+    return 0;
 }
 
 int cart_engine_set_timing(cart_engine *e, int enabled) {
@@ -405,10 +460,14 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     if (fr.out_step < (size_t)g.w * 2 || (fr.out_step & 1)) return fail("out_step must be even and >= 2*width");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(e->params.device_id));
-    if (std::min(n_frames, e->chunk_frames) >= e->fused_min_frames) {
+    int chunk_frames, opt_plan, opt_min;
+    {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (!e->rv_partial) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
+        chunk_frames = e->chunk_frames; opt_plan = e->opt_plan; opt_min = e->opt_plan_min_frames;
+        if (plan_for(e, std::min(n_frames, chunk_frames)) == CART_PLAN_FUSED_UP && !e->rv_partial)
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
     }
+    (void)opt_plan; (void)opt_min;
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
@@ -437,7 +496,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         STAGE("census");
         launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
         STAGE("aggregate");
-        const bool fused = n >= e->fused_min_frames && e->rv_partial;
+        const bool fused = plan_for(e, n) == CART_PLAN_FUSED_UP && e->rv_partial;
         AggArgs a = fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
@@ -469,7 +528,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     // Large batches run as cache-sized sub-batches on the caller's stream: the census planes every direction
     // re-reads (4.2 MB per frame) then stay in L2 + Infinity Cache (measured: 64 frames in one launch are 13 %
     // slower per frame than 4 x 16).  Two-stream overlap of sub-batches was measured and buys nothing.
-    const int chunk = fr.lefts ? std::min(e->chunk_frames, kLaunchFrames) : e->chunk_frames;  // pointer tables hold kLaunchFrames entries
+    const int chunk = fr.lefts ? std::min(chunk_frames, kLaunchFrames) : chunk_frames;  // pointer tables hold kLaunchFrames entries
     for (int f0 = 0; f0 < n_frames; f0 += chunk) enqueue(f0, std::min(chunk, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
     release(l);
@@ -825,6 +884,11 @@ void sp_leave(cart_superpixels *sp, hipStream_t stream) {
     sp->last_stream = stream;
     sp->used = true;
 }
+// records the completion event on every way out of a call, early error returns included
+struct SpScope {
+    cart_superpixels *sp; hipStream_t stream;
+    ~SpScope() { sp_leave(sp, stream); }
+};
 }  // namespace
 
 void cart_superpixel_default_params(cart_superpixel_params *p) {
@@ -874,6 +938,7 @@ int cart_superpixels_create(cart_engine *e, const cart_superpixel_params *params
 
 void cart_superpixels_destroy(cart_superpixels *sp) {
     if (!sp) return;
+    if (sp->engine) (void)hipSetDevice(sp->engine->params.device_id);
     (void)hipDeviceSynchronize();
     void *bufs[] = {sp->labels[0], sp->labels[1], sp->ycc, sp->stats, sp->delta, sp->costs, sp->max_seen};
     for (void *b : bufs)
@@ -891,9 +956,9 @@ int cart_superpixels_reset(cart_superpixels *sp, void *stream_) {
     HIP_TRY(hipSetDevice(sp->engine->params.device_id));
     std::lock_guard<std::mutex> lk(sp->mu);
     if (sp_enter(sp, stream)) return -1;
+    SpScope scope{sp, stream};
     launch_sp_block_init(sp->labels[sp->cur], g.w, g.h, sp->block_w, sp->block_h, stream);
     sp->max_label_id = ((g.w + sp->block_w - 1) / sp->block_w) * ((g.h + sp->block_h - 1) / sp->block_h);
-    sp_leave(sp, stream);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -907,13 +972,13 @@ int cart_superpixels_set_labels(cart_superpixels *sp, const uint16_t *labels, si
     HIP_TRY(hipSetDevice(sp->engine->params.device_id));
     std::lock_guard<std::mutex> lk(sp->mu);
     if (sp_enter(sp, stream)) return -1;
+    SpScope scope{sp, stream};
     // the copy goes to the spare buffer and becomes the state only if every label is in range
     uint16_t *spare = sp->labels[sp->cur ^ 1];
     HIP_TRY(hipMemsetAsync(sp->max_seen, 0, sizeof(int), stream));
     launch_sp_copy(labels, labels_step, spare, (size_t)g.w * 2, g.w, g.h, sp->max_seen, stream);
     int seen = 0;
     HIP_TRY(hipMemcpyAsync(&seen, sp->max_seen, sizeof(int), hipMemcpyDeviceToHost, stream));
-    sp_leave(sp, stream);
     HIP_TRY(hipStreamSynchronize(stream));
     if (seen >= max_label_id) return fail("label image holds a label >= max_label_id");
     sp->cur ^= 1;
@@ -939,6 +1004,7 @@ int cart_superpixels_relax(cart_superpixels *sp, const uint8_t *image, size_t im
     HIP_TRY(hipSetDevice(sp->engine->params.device_id));
     std::lock_guard<std::mutex> lk(sp->mu);
     if (sp_enter(sp, stream)) return -1;
+    SpScope scope{sp, stream};
     const int ld = sp->max_label_id + 1;
     SpRelaxArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -960,7 +1026,6 @@ int cart_superpixels_relax(cart_superpixels *sp, const uint8_t *image, size_t im
         sp->cur ^= 1;
     }
     if (labels_out) launch_sp_copy(sp->labels[sp->cur], (size_t)g.w * 2, labels_out, labels_out_step, g.w, g.h, nullptr, stream);
-    sp_leave(sp, stream);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1098,6 +1163,21 @@ int cart_find_plane_params(const int32_t hist[256], cart_plane_params *io) {
     io->vertical_min = pv - vwidth - 128; io->vertical_max = valley - 127;      // :452
     io->horizontal_min = valley - 127; io->horizontal_max = ph + hwidth - 127;  // :453
     return 1;
+}
+
+int cart_debug_uniq_table(cart_engine *e, int uniqueness_ratio, uint16_t *out2048) {
+    if (!out2048) return fail("bad arguments");
+    if (uniqueness_ratio < 0 || uniqueness_ratio > 100) return fail("uniqueness_ratio must be in [0, 100]");
+    const float u = (float)(100 - uniqueness_ratio) / 100.0f;   // as cart_engine_create (oracle S5)
+    if (!e) { uniq_table_host(u, out2048); return 0; }
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    uint16_t *dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), 2048 * sizeof(uint16_t)));
+    launch_uniq_table(u, dev, nullptr);
+    hipError_t err = hipMemcpy(out2048, dev, 2048 * sizeof(uint16_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (err != hipSuccess) return fail(std::string("uniq table: ") + hipGetErrorString(err));
+    return 0;
 }
 
 int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, size_t bytes) {

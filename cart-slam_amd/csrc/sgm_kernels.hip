@@ -332,7 +332,7 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         uint4 o;
         o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
         o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
-#ifdef CART_ABLATE_STORE  // timing experiment only: keep the bytes live, skip the slab store
+#if defined(CART_EXPERIMENTS) && defined(CART_ABLATE_STORE)  // timing experiment only: keep the bytes live, skip the slab store
         asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
         (void)po;
 #else
@@ -657,7 +657,7 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
 }
 
 // smallest s with (float)s*u >= (float)bc, clamped to 4095 (> any reachable cost sum, <= 8*255)
-__device__ __forceinline__ uint32_t uniq_threshold(uint32_t bc, float u) {
+__host__ __device__ __forceinline__ uint32_t uniq_threshold(uint32_t bc, float u) {
     if (bc == 0) return 0;
     if (!(u > 0.f)) return 4095u;
     const float bcf = (float)bc;
@@ -670,7 +670,18 @@ __device__ __forceinline__ uint32_t uniq_threshold(uint32_t bc, float u) {
         const int v = g + c;
         if (v >= 0 && (float)v * u >= bcf) T = v;
     }
-    return (uint32_t)min(T, 4095);
+    return (uint32_t)(T < 4095 ? T : 4095);
+}
+
+// test access (cart_debug_uniq_table): the threshold of every best cost 0..2047 for one uniqueness ratio, computed by
+// the device code the WTA kernels use, or by the same function compiled for the host
+__global__ void uniq_table_kernel(float u, uint16_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2048) out[i] = (uint16_t)uniq_threshold((uint32_t)i, u);
+}
+void launch_uniq_table(float u, uint16_t *out_dev, hipStream_t s) { hipLaunchKernelGGL(uniq_table_kernel, dim3(8), dim3(256), 0, s, u, out_dev); }
+void uniq_table_host(float u, uint16_t *out) {
+    for (int i = 0; i < 2048; ++i) out[i] = (uint16_t)uniq_threshold((uint32_t)i, u);
 }
 
 template <int LPP>
@@ -797,8 +808,9 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 // The row loop has no block barrier (the LDS sum tile is only read by the wave that wrote it); left disparities and
 // right-view minima are buffered in LDS for 16 rows and written out in one burst between two barriers, so the row
 // loop itself holds loads only and the prefetches stay in flight while a row is processed.
-#ifndef CART_FUSED_ABLATE
-#define CART_FUSED_ABLATE 0   // timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view, 128 no recurrence, 256 no WTA
+#if !defined(CART_EXPERIMENTS) || !defined(CART_FUSED_ABLATE)   // product builds: every experiment hook compiles to nothing
+#undef CART_FUSED_ABLATE
+#define CART_FUSED_ABLATE 0   // -DCART_EXPERIMENTS -DCART_FUSED_ABLATE=mask, timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view, 128 no recurrence, 256 no WTA
 #endif
 // Waves per block of the fused sweep.  The sweep has frames*W/(64/LPP) waves in total (2484 at 16 x 1242, D=128: 2.4 per
 // SIMD), so small blocks spread them evenly over the CUs: with 4-wave blocks a quarter of the CUs carried 3 blocks, the

@@ -1,6 +1,7 @@
 // module.hpp -- the plugin API (drop-in boundary). Mirrors include/modules/module.hpp:14-56 and
 // src/modules/module.cpp:7-19 of the reference with std:: in place of boost:: futures.
 #pragma once
+#include <cstdint>
 #include <future>
 #include <string>
 #include <vector>
@@ -29,6 +30,11 @@ class SystemModule {
     virtual ~SystemModule() = default;
 
     virtual std::future<system_data_t> run(System &system, SystemRunData &data) = 0;
+
+    // Extension over the reference's interface: the System calls this once per frame and module when the module's work
+    // for that frame is over -- after run() returned, threw, or was never started because a dependency failed.  Modules
+    // that admit frames in id order (FrameOrder) use it to pass the turn of a frame that will never take it.
+    virtual void frameFinished(uint32_t /*id*/) noexcept {}
 
     const std::vector<module_dependency_t> getRequiredData() const { return requiresData; }
     const std::vector<std::string> getProvidedData() const { return providesData; }

@@ -108,6 +108,7 @@ class SuperPixelDisparityPlaneSegmentationModule : public SyncWrapperSystemModul
                                                const bool useTemporalSmoothing = false,
                                                const unsigned int temporalSmoothingDistance = CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT);
     system_data_t runInternal(System &system, SystemRunData &data) override;
+    void frameFinished(uint32_t id) noexcept override { order.finish(id); }
 
    private:
     void updatePlaneParameters(System &system, SystemRunData &data);  // sp_planeseg.cu:349-387

@@ -2,6 +2,7 @@
 // contour-relaxation superpixel module (same name, constructor arguments, blackboard keys, error texts).  The
 // ContourRelaxation object with its three features lives behind cart_superpixels_* (include/cart_engine.h).
 #pragma once
+#include <set>
 #include <condition_variable>
 #include <mutex>
 
@@ -17,9 +18,11 @@ typedef uint16_t label_t;  // contourrelaxation/constants.hpp:35
 
 // Stateful modules of the reference take frames in whatever order their lock is won (superpixels.cu:97-99,
 // sp_planeseg.cu:356-371), which makes their output depend on thread timing.  FrameOrder admits frames in id order
-// instead (a frame that never arrives is skipped after a grace period, so a failed frame cannot stall the system).
+// instead.  A frame that never takes its turn (its module failed, or a dependency did) is passed over explicitly: the
+// System reports the end of every frame to the module (SystemModule::frameFinished -> finish), no timer is involved.
 class FrameOrder {
    public:
+    void finish(uint32_t id);   // idempotent: frame `id` has had (or will never take) its turn
     class Turn {
        public:
         Turn(FrameOrder &o, uint32_t id);
@@ -34,6 +37,7 @@ class FrameOrder {
     std::mutex mutex;
     std::condition_variable cv;
     uint32_t next = 1;
+    std::set<uint32_t> finishedAhead;   // ids > next that are already over
 };
 
 class SuperPixelModule : public SyncWrapperSystemModule {
@@ -44,6 +48,7 @@ class SuperPixelModule : public SyncWrapperSystemModule {
                      const double disparityWeight = 1.25);
     ~SuperPixelModule();
     system_data_t runInternal(System &system, SystemRunData &data) override;
+    void frameFinished(uint32_t id) noexcept override { order.finish(id); }
     unsigned int getBlockSize() const { return blockSize; }
 
    private:

@@ -79,6 +79,10 @@ std::future<void> System::run() {
             // returned (key, ptr) pairs go onto the frame's blackboard (cartslam.cpp:279-301)
             done.push_back(std::async(std::launch::async, [this, run, m]() {
                 auto moduleTiming = timing::initTiming(m->name, run->id);  // cartslam.cpp:259-262: init before the dependency wait
+                struct Finished {   // the module hears about the end of this frame on every way out, exceptions included
+                    SystemModule &m; uint32_t id;
+                    ~Finished() { m.frameFinished(id); }
+                } finished{*m, run->id};
                 std::vector<std::string> same_frame;
                 for (const auto &d : m->getRequiredData()) {
                     if (d.runOffset == 0) { same_frame.push_back(d.name); continue; }

@@ -64,37 +64,28 @@ bool frameExists(const std::string &dir, int cam, int frame) {
     return false;
 }
 
-// one "P<id>: 12 numbers" row of calib.txt, tokenised like kitti.cpp:28-86 (the row must hold exactly 12 numbers)
-struct KITTICameraCalibration {
-    int cameraId = -1;
-    float fx = 0, fy = 0, cx = 0, cy = 0, baseline = 0;
+// A projection row of KITTI's calib.txt: "P<camera>: m00 m01 ... m23" (3x4, row-major).  Rows that are not a
+// projection matrix ("Tr: ...") or do not hold exactly twelve numbers are skipped, as kitti.cpp:28-86 skips them.
+struct ProjectionRow {
+    int camera = -1;
+    float m[12] = {};
+    float fx() const { return m[0]; }
+    float cx() const { return m[2]; }
+    float cy() const { return m[6]; }
+    float baseline() const { return -m[3] / m[0]; }   // m[3] = -fx * baseline (kitti.cpp:80)
 };
 
-bool readCalibLine(std::string line, KITTICameraCalibration &calibration) {
-    size_t pos = line.find(": ");
-    if (pos == std::string::npos) return false;
-    std::string token = line.substr(0, pos);
-    line.erase(0, pos + 2);
-    if (token.empty() || token[0] != 'P') return false;
-    KITTICameraCalibration local;
-    local.cameraId = std::atoi(token.c_str() + 1);
-    float fubx = 0;
-    int i = 0;
-    while ((pos = line.find(" ")) != std::string::npos) {
-        token = line.substr(0, pos);
-        line.erase(0, pos + 1);
-        switch (i) {
-            case 0: local.fx = std::stof(token); break;
-            case 5: local.fy = std::stof(token); break;
-            case 3: fubx = std::stof(token); break;
-            case 2: local.cx = std::stof(token); break;
-            case 6: local.cy = std::stof(token); break;
-        }
-        i++;
-    }
-    if (i != 11) return false;
-    local.baseline = -fubx / local.fx;
-    calibration = local;
+bool parseProjectionRow(const std::string &line, ProjectionRow &row) {
+    std::istringstream in(line);
+    std::string label;
+    if (!(in >> label) || label.size() < 3 || label.front() != 'P' || label.back() != ':') return false;
+    ProjectionRow parsed;
+    parsed.camera = std::atoi(label.c_str() + 1);
+    int count = 0;
+    for (float v; in >> v; ++count)
+        if (count < 12) parsed.m[count] = v;
+    if (count != 12 || !in.eof()) return false;   // too few, too many, or something that is not a number
+    row = parsed;
     return true;
 }
 }  // namespace
@@ -167,24 +158,22 @@ KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence) : Da
     dir = basePath + "/sequences/" + seq;  // kitti.cpp:89-90
     const std::string calibPath = dir + "/calib.txt";
     std::ifstream calib(calibPath);
-    KITTICameraCalibration l, r;
+    ProjectionRow cams[2];   // P2 = left colour camera, P3 = right
     if (calib.is_open()) {
-        std::string line;
-        while (std::getline(calib, line)) {
-            KITTICameraCalibration c;
-            if (readCalibLine(line, c)) {
-                if (c.cameraId == 2) l = c;
-                else if (c.cameraId == 3) r = c;
-            }
+        for (std::string line; std::getline(calib, line);) {
+            ProjectionRow row;
+            if (parseProjectionRow(line, row) && (row.camera == 2 || row.camera == 3)) cams[row.camera - 2] = row;
         }
-        if (l.cameraId != 2 || r.cameraId != 3) throw std::runtime_error("Failed to read calibration file");  // kitti.cpp:126-128
+        if (cams[0].camera != 2 || cams[1].camera != 3) throw std::runtime_error("Failed to read calibration file");  // kitti.cpp:126-128
+        const ProjectionRow &l = cams[0], &r = cams[1];
+        const float base = l.baseline();
         float *Q = intrinsics.Q;  // kitti.cpp:139-148 (no resize: scale factors are 1)
-        Q[0 * 4 + 3] = -l.cx;
-        Q[1 * 4 + 3] = -l.cy;
+        Q[0 * 4 + 3] = -l.cx();
+        Q[1 * 4 + 3] = -l.cy();
         Q[2 * 4 + 2] = 0;
-        Q[2 * 4 + 3] = l.fx;
-        Q[3 * 4 + 2] = (float)(-1.0 / l.baseline);
-        Q[3 * 4 + 3] = (l.cx - r.cx) / l.baseline;
+        Q[2 * 4 + 3] = l.fx();
+        Q[3 * 4 + 2] = (float)(-1.0 / base);
+        Q[3 * 4 + 3] = (l.cx() - r.cx()) / base;
     } else if (std::ifstream(framePath(dir, 2, 0, "png")).is_open()) {
         throw std::runtime_error("Failed to open calibration file at " + calibPath + ": " + std::strerror(errno));  // kitti.cpp:100-103
     }
@@ -208,6 +197,8 @@ std::shared_ptr<DataElement> KITTIDataSource::getNextInternal() {
     } else if (!readFrame(dir, 2, currentFrame, l) || !readFrame(dir, 3, currentFrame, r)) {
         throw std::runtime_error("Could not read frame " + std::to_string(currentFrame));
     }
+    if (l.w != r.w || l.h != r.h || l.channels != r.channels)
+        throw std::runtime_error("Frame " + std::to_string(currentFrame) + ": left and right image differ in size or channel count");
     ++currentFrame;
     const int type = l.channels == 3 ? CV_8UC3 : CV_8UC1;
     image_t dl(l.h, l.w, type), dr(r.h, r.w, type);

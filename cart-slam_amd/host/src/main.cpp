@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <deque>
+#include <future>
 #include <fstream>
 #include <iostream>
 
@@ -35,18 +38,22 @@ int main(int argc, char **argv) {
         const size_t inflight = cart::concurrentRunLimit();
         auto system = std::make_shared<cart::System>(dataSource, std::max<size_t>(CARTSLAM_RUN_RETENTION, inflight + 8), inflight);
         cart::config::readModuleConfig(argv[2], system);
-        std::vector<std::future<void>> pending;
-        int frames = 0;
+        std::deque<std::future<void>> pending;   // at most `inflight` + 1 entries: finished frames are reaped as the loop goes
+        int frames = 0, failed = 0;
+        auto reap = [&](bool all) {
+            while (!pending.empty() && (all || pending.front().wait_for(std::chrono::seconds(0)) == std::future_status::ready)) {
+                try { pending.front().get(); } catch (const std::exception &e) { std::cerr << "Error in processing: " << e.what() << "\n"; ++failed; }
+                pending.pop_front();
+            }
+        };
         while (!dataSource->isFinished() && frames < maxFrames) {
             if (!dataSource->isNextReady()) continue;
             pending.push_back(system->run());
             if (sequential) pending.back().wait();
             ++frames;
+            reap(false);
         }
-        int failed = 0;
-        for (auto &f : pending) {
-            try { f.get(); } catch (const std::exception &e) { std::cerr << "Error in processing: " << e.what() << "\n"; ++failed; }
-        }
+        reap(true);
         if (!dump.empty()) {
             const char *keys[] = {CARTSLAM_KEY_DISPARITY, CARTSLAM_KEY_DISPARITY_DERIVATIVE, CARTSLAM_KEY_DISPARITY_DERIVATIVE_HISTOGRAM, CARTSLAM_KEY_PLANES,
                                   CARTSLAM_KEY_PLANE_COMPONENTS, CARTSLAM_KEY_DEPTH, CARTSLAM_KEY_PLANES_UNSMOOTHED, CARTSLAM_KEY_SUPERPIXELS, CARTSLAM_KEY_OPTFLOW,

@@ -432,15 +432,18 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
 // ---------------------------------------------------------------- superpixels (superpixels.cu:19-118)
 FrameOrder::Turn::Turn(FrameOrder &o, uint32_t id) : order(o), id(id) {
     std::unique_lock<std::mutex> lock(order.mutex);
-    while (order.next < id)
-        if (order.cv.wait_for(lock, std::chrono::seconds(5)) == std::cv_status::timeout && order.next < id) ++order.next;  // an earlier frame never came
+    order.cv.wait(lock, [&] { return order.next >= id; });   // every earlier frame has finished, one way or the other
 }
-FrameOrder::Turn::~Turn() {
+FrameOrder::Turn::~Turn() { order.finish(id); }
+
+void FrameOrder::finish(uint32_t id) {
     {
-        std::lock_guard<std::mutex> lock(order.mutex);
-        if (order.next <= id) order.next = id + 1;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (id < next) return;
+        finishedAhead.insert(id);
+        while (!finishedAhead.empty() && *finishedAhead.begin() == next) { finishedAhead.erase(finishedAhead.begin()); ++next; }
     }
-    order.cv.notify_all();
+    cv.notify_all();
 }
 
 SuperPixelModule::SuperPixelModule(const Size imageRes, const unsigned int initialIterations, const unsigned int iterations, const unsigned int blockSize,

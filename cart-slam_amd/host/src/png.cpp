@@ -31,6 +31,7 @@ bool readPng(const std::string &path, HostImage &out) {
         if (pos + 12 + len > file.size()) throw std::runtime_error("truncated PNG chunk: " + path);
         const uint8_t *body = &file[pos + 8];
         if (!std::memcmp(type, "IHDR", 4)) {
+            if (len < 13) throw std::runtime_error("short PNG header chunk: " + path);
             w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
         } else if (!std::memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), body, body + len);

@@ -66,6 +66,31 @@ void cart_engine_default_params(cart_engine_params *p);
 int cart_engine_create(const cart_engine_params *params, cart_engine **out);
 void cart_engine_destroy(cart_engine *engine);
 
+/* Launch plans of the SGM core.  Every plan produces the same bits; they differ in which path slabs exist in HBM.
+ *   SLABS     all P path slabs are written by the aggregation launch and read by the WTA launch (2*P*D bytes / pixel);
+ *   FUSED_UP  the "up" path is computed inside the WTA sweep and never stored (2*(P-1)*D bytes / pixel);
+ *   PAIRS     (8 paths) {down, down-right} leave ONE u8 slab holding the sum of their penalty parts, {up, up-left} are
+ *             computed inside the WTA sweep: 5 slabs instead of 8 (2*5*D bytes / pixel).  Needs 2*p2 <= 255; other
+ *             engines fall back to FUSED_UP.
+ * AUTO picks per launch from the measured table in DESIGN.md section 4.  Options are plain integers so that the
+ * boundary stays C; nothing in the engine reads the environment. */
+enum { CART_PLAN_AUTO = -1, CART_PLAN_SLABS = 0, CART_PLAN_FUSED_UP = 1, CART_PLAN_PAIRS = 2 };
+enum {
+    CART_OPT_PLAN = 0,            /* CART_PLAN_*; default AUTO */
+    CART_OPT_PLAN_MIN_FRAMES = 1, /* with a forced plan: launches of fewer frames take SLABS (default 1) */
+    CART_OPT_CHUNK_FRAMES = 2     /* frames per launch sequence inside one batched call (default 16, 1..64) */
+};
+int cart_engine_set_option(cart_engine *engine, int option, int value);
+int cart_engine_get_option(cart_engine *engine, int option, int *value);
+/* What a batched call of n_frames will do: frames per launch sequence, the plan of a full launch, and the number of
+ * path slabs that plan materialises (bench.py prices its roofline line from this instead of re-deriving it). */
+typedef struct {
+    int frames_per_launch;
+    int plan;             /* CART_PLAN_SLABS | FUSED_UP | PAIRS */
+    int slabs_written;    /* u8 slabs of D bytes per pixel written (and read once) per frame */
+} cart_launch_plan;
+int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_plan *out);
+
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
  * create when engine == NULL).  Never NULL. */
 const char *cart_last_error(const cart_engine *engine);
@@ -280,6 +305,13 @@ enum {
     CART_DBG_WTA_L = 32, CART_DBG_WTA_R = 33      /* u16 [h][w]              */
 };
 int cart_debug_read(cart_engine *engine, int frame_slot, int what, void *host_dst, size_t bytes);
+
+/* Test access to the integer form of the uniqueness test.  The WTA kernels replace the float compare
+ * (float)S * u >= (float)best (u = (100 - uniqueness_ratio) / 100.0f) by S >= T(best); this returns T for every
+ * best = 0..2047 (sums of <= 8 paths of <= 255 stay below 2048), clamped to 4095 where no reachable S passes.
+ * engine != NULL: computed on its GPU by the kernels' own device function; engine == NULL: the same function
+ * compiled for the host.  out2048 is a HOST array. */
+int cart_debug_uniq_table(cart_engine *engine, int uniqueness_ratio, uint16_t *out2048);
 
 /* Per-stage device time (hipEvents recorded on the caller's stream around each stage of
  * cart_compute_disparity[_batch]).  set_timing(1) enables recording and clears the record ring

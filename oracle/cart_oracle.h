@@ -36,6 +36,20 @@
  *                 not unique -> 0xFFFF.  Sub-pixel (x16): if 0<best<D-1,
  *                 num = S[b-1]-S[b+1], den = S[b-1]-2S[b]+S[b+1],
  *                 disp = 16*b + (den ? (16*num+den)/(2*den) : 0)  (C truncation).
+ *                 NOTE -- departs from the wording of SURVEY.md 8a-4(4), which describes the
+ *                 test from upstream memory as "top-2 tracking: keep iff cost2*u >= cost1 or
+ *                 |d2-d1| <= 1" (only the SECOND-best cost is examined).  The two differ
+ *                 when the second-best cost sits next to the best (|d2-d1| <= 1, so top-2
+ *                 keeps the pixel) while a third, non-adjacent disparity also fails the
+ *                 ratio: S5 then rejects the pixel, top-2 keeps it.  S5 is the form of the
+ *                 published libSGM winner-takes-all kernel that cv::cuda::StereoSGM is
+ *                 built from (every lane evaluates "cost*u >= best || |d-best| <= 1" and
+ *                 the results are AND-reduced over the whole disparity range); the survey
+ *                 text is a paraphrase, marked [EXTERNAL-UNVERIFIED] there.  Neither form
+ *                 can be checked against the reference here (opencv_contrib is absent, no
+ *                 fixtures): parity unpinned.  Should a reference-side fixture ever show
+ *                 the top-2 form, this line and wta's uniqueness loop are the one place to
+ *                 change.
  *  S6 WTA right R(p) = argmin_d S(p+d, d) over d with p+d < W, ties -> lowest d,
  *                 integer disparity (not x16), never invalid.
  *  S7 median    3x3 on both maps as u16 (0xFFFF sorts highest); the one-pixel

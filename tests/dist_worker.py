@@ -1,0 +1,76 @@
+"""One rank of the two-rank engine rehearsal (tests/test_gpu_sequence.py starts it as a fresh child process per rank).
+
+  python dist_worker.py <rank> <world> <port> <out.npz> <w> <h> <D> <P> <n_local> <steps> <ui> <ri> <device_schedule>
+
+Every rank drives the REAL engine through StereoPipeline (process_batch for `steps` steps, then one process_sequence whose
+frames start on rank 0) with the gloo backend, all ranks on cuda:0 -- the frame sharding, the histogram all-gather, the
+permute to id order, the device / host plane-parameter schedule and the scatter/gather of the sequence mode are the
+product code of cartslam/pipeline.py; only the transport differs from RCCL."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "cart-slam_amd"))
+
+
+def frames_of(ids, w, h, D, seed):
+    from cartslam import synth
+    ls, rs = [], []
+    for i in ids:
+        l, r, _ = synth.make_pair(w, h, D, 4, seed, i - 1)
+        ls.append(l); rs.append(r)
+    return np.stack(ls), np.stack(rs)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    out_path = sys.argv[4]
+    w, h, D, P, n_local, steps, ui, ri, dev_sched = [int(v) for v in sys.argv[5:14]]
+    import torch
+    import torch.distributed as dist
+    from cartslam import Engine
+    from cartslam.pipeline import StereoPipeline, shard_ids
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n_local)
+        pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True,
+                              device_schedule=bool(dev_sched), overlap=bool(dev_sched))   # the bench's mode when the schedule is on the device
+        res = {}
+        next_id = 1
+        for s in range(steps):
+            ids = shard_ids(next_id, n_local, rank, world)
+            ls, rs = frames_of(ids, w, h, D, 4321)
+            o = pipe.process_batch(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda())
+            torch.cuda.synchronize()
+            for k, fid in enumerate(ids):
+                res[f"disp_{fid}"] = o["disparity"][k].cpu().numpy()
+                res[f"planes_{fid}"] = o["planes"][k].cpu().numpy()
+                res[f"ids_{fid}"] = o["ids"][k].cpu().numpy()
+                res[f"ncomp_{fid}"] = np.int32(o["n_components"][k].item())
+            next_id += n_local * world
+        # sequence mode (BASELINE configs[4]): the frames start on rank 0, outputs come back to rank 0 in sequence order
+        n_seq = n_local * world
+        sl = sr = None
+        if rank == 0:
+            ls, rs = frames_of(range(next_id, next_id + n_seq), w, h, D, 4321)
+            sl, sr = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+        got = pipe.process_sequence(sl, sr, n_seq)
+        torch.cuda.synchronize()
+        if rank == 0:
+            res["seq_first_id"] = np.int32(next_id)
+            res["seq_disp"] = got["disparity"].cpu().numpy()
+            res["seq_planes"] = got["planes"].cpu().numpy()
+        else:
+            assert got["disparity"] is None and got["planes"] is None
+        np.savez(out_path, **res)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

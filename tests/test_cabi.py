@@ -91,3 +91,37 @@ def test_every_entry_point_rejects_null_arguments():
         assert lib.cart_last_error(None), name
         checked += 1
     assert checked >= 25
+
+
+def _uniq_threshold_reference(ratio):
+    """T(best) = min{ s : (float)s * u >= (float)best } by brute force over s = 0..4095 in float32 -- the float compare
+    of oracle S5 (oracle/cart_oracle.c, cart_oracle_wta) solved for s; 4095 where no s passes."""
+    u = np.float32(100 - ratio) / np.float32(100.0)
+    s = np.arange(4096, dtype=np.float32) * u                   # float32 products, like the kernels' (float)s * u
+    best = np.arange(2048, dtype=np.float32)
+    ok = s[None, :] >= best[:, None]
+    return np.where(ok.any(axis=1), ok.argmax(axis=1), 4095).astype(np.uint16)
+
+
+def _check_uniq_table(got, ratio):
+    """got[best] for best = 0..2047.  Reachable sums are <= 8 * 255 = 2040, so (a) wherever the true threshold is
+    reachable the table must hold exactly it (above, the kernels clamp to 4095 = "no S passes"), and (b) -- the property
+    the kernels use -- S >= T(best) must equal the float compare for EVERY best <= 2040 and S <= 2040."""
+    exp = _uniq_threshold_reference(ratio)
+    reach = np.arange(2048) <= 2040
+    exact = (got == exp) | ((exp > 2040) & (got > 2040))
+    assert exact[reach].all(), f"ratio {ratio}: first mismatch at best = {int(np.argmax(~exact & reach))}"
+    u = np.float32(100 - ratio) / np.float32(100.0)
+    S = np.arange(2041, dtype=np.int64)
+    lhs = S[None, :] >= got.astype(np.int64)[:2041, None]
+    rhs = (S.astype(np.float32) * u)[None, :] >= np.arange(2041, dtype=np.float32)[:, None]
+    assert (lhs == rhs).all(), f"ratio {ratio}: integer test and float compare disagree"
+
+
+def test_integer_uniqueness_threshold_is_the_float_compare_exhaustively():
+    """DESIGN section 4 claims the WTA kernels' integer threshold equals the float uniqueness compare: enumerated here for
+    every best cost 0..2040, every S 0..2040 and every uniqueness ratio 0..100 (host-compiled copy of the device function;
+    the GPU twin of this test is tests/test_gpu_parity.py::test_integer_uniqueness_threshold_on_device)."""
+    from cartslam.engine import uniq_table
+    for ratio in range(101):
+        _check_uniq_table(uniq_table(ratio), ratio)

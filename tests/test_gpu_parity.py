@@ -27,10 +27,13 @@ def dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def make_engine(w, h, D, P, md=4, radius=-1, iters=5, inflight=4, **kw):
+def make_engine(w, h, D, P, md=4, radius=-1, iters=5, inflight=4, plan=None, plan_min_frames=1, **kw):
     from cartslam import Engine
-    return Engine(w, h, num_disparities=D, paths=P, min_disparity=md, smoothing_radius=radius,
-                  smoothing_iterations=iters, max_inflight=inflight, **kw)
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=md, smoothing_radius=radius,
+                 smoothing_iterations=iters, max_inflight=inflight, **kw)
+    if plan is not None:   # force a launch plan (every plan must give the same bits)
+        eng.set_plan(plan, plan_min_frames)
+    return eng
 
 
 CASES = [
@@ -280,6 +283,20 @@ def test_full_size_against_oracle(torch_cuda, w, h, D, P):
     eb, eh = O.plane_derivative(exp)
     assert (pd.cpu().numpy() == eb).all() and (hist.cpu().numpy() == eh).all()
     assert int(hist.sum()) <= w * h
+    # ... and on through the plane-parameter provider, classification, connected components and the component table
+    ok, pp = O.histogram_peak_params(eh)
+    assert ok, "the synthetic scene must give two histogram peaks"
+    planes = eng.plane_classify(pd, pp)
+    ep = O.classify(eb, pp)
+    assert (planes.cpu().numpy() == ep).all(), "planes"
+    assert {0, 1, 2} <= set(np.unique(ep).tolist()), "the label map should hold all three classes"
+    ids, ncomp = eng.plane_ccl(planes)
+    eids, en = O.ccl(ep)
+    assert (ids.cpu().numpy() == eids).all() and int(ncomp.item()) == en, "component ids / count"
+    cap = 1 << 15
+    table, n2 = eng.plane_ccl_stats(planes, ids, max_components=cap)
+    et, _ = O.ccl_stats(ep, eids, max_components=cap)
+    assert int(n2.item()) == en and en <= cap and (table.cpu().numpy()[:len(et)] == et).all(), "component table"
     eng.close()
 
 
@@ -406,16 +423,13 @@ def test_reproject_depth_batched(torch_cuda):
     eng.close()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_randomized_configurations(torch_cuda, fused, monkeypatch):
+@pytest.mark.parametrize("plan", ["slabs", "fused_up", "pairs"])
+def test_randomized_configurations(torch_cuda, plan):
     """Seeded sweep over sizes / D / paths / min_disparity / P1 / P2 / uniqueness / smoothing, incl. the extremes
     (uniqueness 0 and 100, min_disparity 0 and 64, width < D, 1-pixel-ragged tiles); every output bit-exact -- once
-    through the two-kernel WTA and once with the fused WTA forced for every call."""
+    per launch plan, each forced for every call (engines that cannot take "pairs" -- 4 paths or 2*P2 > 255 -- fall
+    back to "fused_up" by contract)."""
     torch = torch_cuda
-    if fused:
-        monkeypatch.setenv("CART_FUSED_MIN_FRAMES", "1")
-    else:
-        monkeypatch.setenv("CART_FUSED_WTA", "0")
     rng = np.random.default_rng(20260101)
     cases = []
     for i in range(28):
@@ -435,7 +449,7 @@ def test_randomized_configurations(torch_cuda, fused, monkeypatch):
             r = rng.integers(0, 256, l.shape).astype(np.uint8)
         else:
             l, r, _ = synth.make_pair(w, h, D, md, seed=1000 + k, channels=ch)
-        eng = make_engine(w, h, D, P, md, radius=radius, iters=iters, inflight=2, p1=p1, p2=p2, uniqueness_ratio=uniq)
+        eng = make_engine(w, h, D, P, md, radius=radius, iters=iters, inflight=2, plan=plan, p1=p1, p2=p2, uniqueness_ratio=uniq)
         got = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
         exp = O.disparity_module(l, r, D, P, md, p1=p1, p2=p2, uniq=uniq, radius=radius, iterations=iters)
         assert (got == exp).all(), f"case {k}: {(w, h, D, P, md, p1, p2, uniq, radius, iters, ch)}: {int((got != exp).sum())} pixels differ"
@@ -535,12 +549,11 @@ FUSED_CASES = [
 
 
 @pytest.mark.parametrize("w,h,D,P,md,n", FUSED_CASES)
-def test_fused_wta_path(torch_cuda, w, h, D, P, md, n, monkeypatch):
+def test_fused_wta_path(torch_cuda, w, h, D, P, md, n):
     """Batches take the WTA kernel that computes the "up" direction on the fly (its slab is never written): the
     remaining slabs, both WTA maps and the disparity must still equal the oracle's, for every frame of the batch."""
     torch = torch_cuda
-    monkeypatch.setenv("CART_FUSED_MIN_FRAMES", "1")  # read at engine creation
-    eng = make_engine(w, h, D, P, md, inflight=max(n, 2))
+    eng = make_engine(w, h, D, P, md, inflight=max(n, 2), plan="fused_up")
     ls, rs = synth.make_batch(n, w, h, D, md, seed=4000 + w)
     disp = eng.compute_disparity(dev(torch, ls), dev(torch, rs)).cpu().numpy()
     for f in range(n):
@@ -560,20 +573,21 @@ def test_fused_wta_path(torch_cuda, w, h, D, P, md, n, monkeypatch):
     eng.close()
 
 
-def test_fused_and_two_kernel_paths_agree_at_full_size(torch_cuda, monkeypatch):
+def test_launch_plans_agree_at_full_size(torch_cuda):
     torch = torch_cuda
     w, h, D, P, n = 1242, 375, 128, 8, 8
     ls, rs = synth.make_batch(2, w, h, D, 4, seed=31)
     L = dev(torch, np.concatenate([ls] * 4)); R = dev(torch, np.concatenate([rs] * 4))
-    monkeypatch.setenv("CART_FUSED_WTA", "0")
-    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n, plan="slabs")
+    assert eng.describe_plan(n) == {"frames_per_launch": n, "plan": "slabs", "slabs_written": 8}
     a = eng.compute_disparity(L, R).cpu().numpy()
+    for plan, slabs in (("fused_up", 7), ("pairs", 5)):
+        eng.set_plan(plan)
+        assert eng.describe_plan(n) == {"frames_per_launch": n, "plan": plan, "slabs_written": slabs}
+        b = eng.compute_disparity(L, R).cpu().numpy()
+        assert (a == b).all(), plan
     eng.close()
-    monkeypatch.setenv("CART_FUSED_WTA", "1")
-    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)  # forced: fused from 8 frames up (default for D=256 only)
-    b = eng.compute_disparity(L, R).cpu().numpy()
-    eng.close()
-    assert (a == b).all() and (a[0] == a[2]).all() and (a[0] != a[1]).any()
+    assert (a[0] == a[2]).all() and (a[0] != a[1]).any()
     assert (a[0] == O.disparity_module(ls[0], rs[0], D, P, 4, radius=2, iterations=1)).all()
 
 
@@ -781,4 +795,18 @@ def test_full_size_oracle_1080p_d256(torch_cuda):
     for k in range(4):
         assert (got[k] == want[k % 2]).all(), f"batch frame {k}: {int((got[k] != want[k % 2]).sum())} pixels differ"
     assert (eng.compute_disparity(L[1], R[1]).cpu().numpy() == want[1]).all(), "single pair"
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_integer_uniqueness_threshold_on_device(torch_cuda):
+    """The device function behind the WTA kernels' uniqueness test, enumerated over its whole domain (best cost 0..2047 x
+    ratio 0..100) against the float compare it replaces."""
+    from cartslam.engine import uniq_table
+    from test_cabi import _check_uniq_table
+    eng = make_engine(64, 32, 64, 4)
+    for ratio in range(101):
+        got = uniq_table(ratio, eng)
+        _check_uniq_table(got, ratio)
+        assert (got == uniq_table(ratio)).all(), f"device and host copies differ at ratio {ratio}"
     eng.close()

@@ -1,0 +1,133 @@
+"""GPU tests (-m gpu) of the batched-sequence configuration (BASELINE.json configs[4]) and of the frame-sharded driver
+with the real engine in every rank.
+
+* 64 frames, 1242x375, D=128, 8 paths, through StereoPipeline in 4 batches of 16 with the reference's update interval
+  (30), so that the plane-parameter refresh at ids 1, 31, 61 (src/modules/planeseg/planeseg.cu:381-395) is crossed at
+  full size; disparity, planes, component ids / count / table of a subset of the frames against the oracle.
+* two ranks (gloo, both on cuda:0, fresh child processes) against a single-process run of the same frames."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from cartslam import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_sequence_64_frames_full_size():
+    import torch
+    from cartslam import Engine
+    from cartslam.pipeline import StereoPipeline
+    w, h, D, P, n, B = 1242, 375, 128, 8, 64, 16
+    check = [1, 2, 30, 31, 32, 61, 64]
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * B)
+    assert eng.describe_plan(B)["frames_per_launch"] == B
+    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=True, keep_hists=True)   # the bench's configuration
+    outs, frames = [], {}
+    for b0 in range(0, n, B):
+        ls, rs = synth.make_batch(B, w, h, D, 4, first_frame=b0)
+        for fid in check:
+            if b0 < fid <= b0 + B:
+                frames[fid] = (ls[fid - 1 - b0], rs[fid - 1 - b0])
+        got = pipe.process_sequence(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda(), B,
+                                    keys=("disparity", "planes", "ids", "n_components", "components", "hists", "params"))
+        outs.append(got)
+    torch.cuda.synchronize()
+    cat = lambda k: np.concatenate([o[k].cpu().numpy() for o in outs])
+    disp, planes, ids, ncomp, comps, hists, params = (cat(k) for k in ("disparity", "planes", "ids", "n_components", "components", "hists", "params"))
+    assert disp.shape == (n, h, w) and hists.shape == (n, 256)
+    # the oracle's disparity / derivative / histogram of the checked frames ...
+    exp = {}
+    for fid in check:
+        l, r = frames[fid]
+        ed = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+        assert (disp[fid - 1] == ed).all(), f"disparity of frame {fid}: {int((disp[fid - 1] != ed).sum())} pixels differ"
+        dd, eh = O.plane_derivative(ed)
+        assert (hists[fid - 1] == eh).all(), f"histogram of frame {fid}"
+        exp[fid] = dd
+    # ... the reference's bookkeeping over ALL 64 per-frame histograms (the GPU's, equal to the oracle's on the checked
+    # frames and covered at this size by test_full_size_against_oracle) with the oracle's peak finder ...
+    cum = np.zeros(256, np.int64)
+    p = (0, 0, 0, 0, 0, 0)
+    refreshed = []
+    for fid in range(1, n + 1):
+        cum += hists[fid - 1]
+        if fid % 30 == 1:   # planeseg.cu:381
+            h32 = cum.astype(np.int32)
+            if fid % 300 == 1:   # :391-394
+                cum[:] = 0
+            ok, p = O.histogram_peak_params(h32, p)
+            refreshed.append((fid, ok, p))
+        assert tuple(int(v) for v in params[fid - 1]) == tuple(p), f"plane parameters of frame {fid}"
+        # ... and classification, components and the component table of the checked frames
+        if fid in exp:
+            ep = O.classify(exp[fid], p)
+            assert (planes[fid - 1] == ep).all(), f"planes of frame {fid}"
+            eids, en = O.ccl(ep)
+            assert (ids[fid - 1] == eids).all() and int(ncomp[fid - 1]) == en, f"components of frame {fid}"
+            et, _ = O.ccl_stats(ep, eids, max_components=4096)
+            m = min(len(et), 4096)
+            assert (comps[fid - 1][:m] == et[:m]).all(), f"component table of frame {fid}"
+    assert [f for f, _, _ in refreshed] == [1, 31, 61]
+    assert any(ok for _, ok, _ in refreshed), "the schedule never produced parameters"
+    assert len({tuple(int(v) for v in row) for row in params}) >= 2, "the refresh at id 31 / 61 changed nothing: the test would not see a wrong schedule"
+    eng.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.parametrize("device_schedule", [1, 0])
+def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
+    """tests/dist_worker.py x 2 (gloo, one GPU) vs one process: every frame of every step and of the sequence call."""
+    import torch
+    from cartslam import Engine
+    from cartslam.pipeline import StereoPipeline
+    from dist_worker import frames_of
+    world, w, h, D, P, n_local, steps, ui, ri = 2, 256, 96, 64, 8, 3, 3, 4, 2   # 18 + 6 frames: refreshes at ids 1, 5, 9, 13, 17, 21; resets at 9, 17
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(world):
+        cmd = [sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), str(tmp_path / f"rank{r}.npz")] + \
+              [str(v) for v in (w, h, D, P, n_local, steps, ui, ri, device_schedule)]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for r, pr in enumerate(procs):
+        out, _ = pr.communicate(timeout=540)
+        assert pr.returncode == 0, f"rank {r} failed:\n{out.decode(errors='replace')[-3000:]}"
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    # single process, same frames in id order, same batch boundaries in ids
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n_local * world)
+    pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True, device_schedule=bool(device_schedule))
+    n_step = n_local * world
+    total = n_step * (steps + 1)
+    seen = 0
+    for s in range(steps + 1):
+        ids = list(range(s * n_step + 1, (s + 1) * n_step + 1))
+        ls, rs = frames_of(ids, w, h, D, 4321)
+        o = pipe.process_batch(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda())
+        torch.cuda.synchronize()
+        for k, fid in enumerate(ids):
+            d1, p1 = o["disparity"][k].cpu().numpy(), o["planes"][k].cpu().numpy()
+            if s < steps:
+                z = ranks[(fid - 1) % world]   # frame f -> rank (f - first) mod world
+                assert (z[f"disp_{fid}"] == d1).all(), f"disparity frame {fid}"
+                assert (z[f"planes_{fid}"] == p1).all(), f"planes frame {fid}"
+                assert (z[f"ids_{fid}"] == o["ids"][k].cpu().numpy()).all() and int(z[f"ncomp_{fid}"]) == int(o["n_components"][k].item()), f"ccl frame {fid}"
+            else:
+                z = ranks[0]
+                assert int(z["seq_first_id"]) == ids[0]
+                assert (z["seq_disp"][k] == d1).all(), f"sequence disparity frame {fid}"
+                assert (z["seq_planes"][k] == p1).all(), f"sequence planes frame {fid}"
+            seen += 1
+    assert seen == total
+    assert "seq_disp" not in ranks[1].files
+    eng.close()
