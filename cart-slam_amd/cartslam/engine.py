@@ -94,6 +94,12 @@ class Engine:
         return {"frames_per_launch": lp.frames_per_launch, "plan": {0: "slabs", 1: "fused_up", 2: "pairs"}[lp.plan],
                 "slabs_written": lp.slabs_written}
 
+    def device_status(self):
+        """Synchronises; 0 = healthy (bit 0: a pair sweep timed out waiting for its neighbour block)."""
+        st = C.c_uint(0)
+        self._check(self._lib.cart_engine_device_status(self._h, C.byref(st)), "cart_engine_device_status")
+        return st.value
+
     # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
     def compute_disparity(self, left, right, out=None):
         import torch

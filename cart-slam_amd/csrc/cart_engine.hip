@@ -72,6 +72,11 @@ struct cart_engine {
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
+    AggArgs agg_pairs;              // plan PAIRS: right, left, down-left, up-left (the other four ride on the two pair sweeps)
+    unsigned long long *pair_xch = nullptr;  // [max_inflight][pair_xch_elems]: block-to-block hand-over of the pair sweeps; first PAIRS call allocates
+    uint32_t *pair_ticket = nullptr;         // [max_inflight] block tickets (a lease uses the counter of its first slot)
+    uint32_t *dev_status = nullptr;          // device status word (cart_engine_device_status)
+    uint32_t pair_epoch = 0;                 // guarded by mu; tags the hand-over words of one sweep launch
     int auto_fused_min_frames = 1 << 30; // CART_OPT_PLAN = auto: launches of at least this many frames take the fused WTA
     int opt_plan = CART_PLAN_AUTO;       // cart_engine_set_option
     int opt_plan_min_frames = 1;         // with a forced plan: launches of fewer frames still take CART_PLAN_SLABS
@@ -196,7 +201,10 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
 // The launch plan of `n` frames handed to one launch sequence (include/cart_engine.h, CART_PLAN_*).
 int plan_for(const cart_engine *e, int n) {
     if (e->opt_plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
-    return n >= e->opt_plan_min_frames ? e->opt_plan : CART_PLAN_SLABS;
+    if (n < e->opt_plan_min_frames) return CART_PLAN_SLABS;
+    // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP
+    if (e->opt_plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255)) return CART_PLAN_FUSED_UP;
+    return e->opt_plan;
 }
 
 int validate(const cart_engine_params *p) {
@@ -303,6 +311,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
         }
     build_agg_args(e, e->agg, 0xffu);
     build_agg_args(e, e->agg_fused, 0xffu & ~(1u << 3));  // launch-order slot 3 = {0,-1} = "up" (slab kFusedUpPath)
+    build_agg_args(e, e->agg_pairs, 0x63u);               // launch-order slots 0, 1 (right, left), 5 (down-left), 6 (up-left)
     // Fused WTA (the "up" direction computed inside the WTA sweep, 1/P less slab traffic): measured on MI355X at
     // 1242x375, batch 16 (profiles/tools/disparity_only.py): D=256 -9 % (4 paths) / -15 % (8 paths) per batch, D=128
     // even, D=64 +4..6 %; D=256 batches of 4 frames: +5 % at 1242x375, -11 % at 1920x1080 -- so it is the default for
@@ -320,7 +329,8 @@ void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
+                    e->pair_xch, e->pair_ticket, e->dev_status};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots)
@@ -378,6 +388,16 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
     out->frames_per_launch = std::min(n_frames, e->chunk_frames);
     out->plan = plan_for(e, out->frames_per_launch);
     out->slabs_written = out->plan == CART_PLAN_PAIRS ? 5 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
+    return 0;
+}
+
+int cart_engine_device_status(cart_engine *e, unsigned *status) {
+    if (!e || !status) return fail("bad arguments");
+    *status = 0;
+    if (!e->dev_status) return 0;   // no kernel that can raise it has run
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(status, e->dev_status, sizeof(unsigned), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -464,8 +484,20 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     {
         std::lock_guard<std::mutex> lk(e->mu);
         chunk_frames = e->chunk_frames; opt_plan = e->opt_plan; opt_min = e->opt_plan_min_frames;
-        if (plan_for(e, std::min(n_frames, chunk_frames)) == CART_PLAN_FUSED_UP && !e->rv_partial)
+        const int launch_plan = plan_for(e, std::min(n_frames, chunk_frames));
+        if (launch_plan == CART_PLAN_FUSED_UP && !e->rv_partial)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
+        if (launch_plan == CART_PLAN_PAIRS && !e->pair_xch) {
+            // zeroed once: epoch 0 never tags a launch, so a word that was never written cannot pass for a hand-over
+            const size_t words = 2 * e->slots.size() * pair_xch_elems(g);   // one area per sweep direction: they run concurrently
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_ticket), 2 * e->slots.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(e->pair_ticket, 0, 2 * e->slots.size() * sizeof(uint32_t)));
+
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dev_status), sizeof(uint32_t)));
+            HIP_TRY(hipMemset(e->dev_status, 0, sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_xch), words * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(e->pair_xch, 0, words * sizeof(unsigned long long)));
+        }
     }
     (void)opt_plan; (void)opt_min;
     Lease l;
@@ -495,13 +527,34 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         if (!timed) rec = nullptr;
         STAGE("census");
         launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
-        STAGE("aggregate");
-        const bool fused = plan_for(e, n) == CART_PLAN_FUSED_UP && e->rv_partial;
-        AggArgs a = fused ? e->agg_fused : e->agg;
+        const int launch_plan = plan_for(e, n);
+        const bool pairs = launch_plan == CART_PLAN_PAIRS && e->pair_xch;
+        const bool fused = launch_plan == CART_PLAN_FUSED_UP && e->rv_partial;
+        STAGE(pairs ? "pair_down" : "aggregate");
+        if (pairs) {
+            // {down, down-right} -> slab 0, {up, up-right} -> slab 1 (penalty sums); slab 4 takes the stores of columns >= w
+            uint32_t epoch;
+            {
+                std::lock_guard<std::mutex> lk(e->mu);
+                e->pair_epoch += 2;
+                if (e->pair_epoch == 0) e->pair_epoch = 2;   // epoch 0 is the never-written state
+                epoch = e->pair_epoch;
+            }
+            // Both sweeps on the caller's stream, one after the other.  Running them on side streams beside the 4-direction
+            // launch was measured (profiles/README.md, round 2): 3.8 instead of 3.6 ms per 16 pairs -- resident blocks that wait
+            // for their neighbour hold their wave slots, so the other kernels do not get the idle issue slots.
+            for (int k = 0; k < 2; ++k) {
+                unsigned long long *xch = e->pair_xch + (2 * s0 + k * (size_t)n) * pair_xch_elems(g);
+                launch_pair_sweep(cl, cr, slabs, xch, e->pair_ticket + 2 * s0 + k, e->dev_status, g, epoch + k, k == 0 ? +1 : -1, k, 4, n, st);
+                STAGE(k == 0 ? "pair_up" : "aggregate");
+            }
+        }
+        AggArgs a = pairs ? e->agg_pairs : fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
         STAGE("wta");
-        if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
+        if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq, n, st);
+        else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
         else launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
         STAGE("post");
         if (!smooth) {

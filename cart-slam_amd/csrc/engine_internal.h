@@ -79,6 +79,12 @@ int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is 
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s);
+// plan PAIRS (sgm_kernels.hip): one sweep per vertical direction carries that direction and the diagonal leaning the same way
+size_t pair_xch_elems(const Geometry &g);   // 8-byte words of the per-frame hand-over buffer
+void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
+                       const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s);
+void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
+                      const Geometry &g, float uniq, int n_frames, hipStream_t s);
 // WTA fused with the "up" direction (slab kFusedUpPath is never read: the aggregate launch may skip that direction)
 constexpr int kFusedUpPath = 1;
 size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer

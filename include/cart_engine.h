@@ -91,6 +91,12 @@ typedef struct {
 } cart_launch_plan;
 int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_plan *out);
 
+/* Synchronises the device and returns the engine's device status word: 0 = healthy.  Bit 0: a pair sweep (plan PAIRS)
+ * gave up waiting for the hand-over of its left neighbour block (bounded poll, so that a grid always drains); the
+ * disparities of that call are then invalid.  It cannot happen on a healthy device; callers that want to know (tests,
+ * the module adapter after its stream synchronise) ask here. */
+int cart_engine_device_status(cart_engine *engine, unsigned *status);
+
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
  * create when engine == NULL).  Never NULL. */
 const char *cart_last_error(const cart_engine *engine);

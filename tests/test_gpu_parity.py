@@ -296,7 +296,7 @@ def test_full_size_against_oracle(torch_cuda, w, h, D, P):
     cap = 1 << 15
     table, n2 = eng.plane_ccl_stats(planes, ids, max_components=cap)
     et, _ = O.ccl_stats(ep, eids, max_components=cap)
-    assert int(n2.item()) == en and en <= cap and (table.cpu().numpy()[:len(et)] == et).all(), "component table"
+    assert int(n2.item()) == en and en <= cap and (table.cpu().numpy().reshape(-1, 7)[:len(et)] == et).all(), "component table"
     eng.close()
 
 
@@ -567,6 +567,49 @@ def test_fused_wta_path(torch_cuda, w, h, D, P, md, n):
             S += L
         wl, wr = O.wta(S, 12)
         assert (eng.debug_read(32, frame_slot=f) == wl).all(), f"frame {f} wta left: {int((eng.debug_read(32, frame_slot=f) != wl).sum())} differ"
+        assert (eng.debug_read(33, frame_slot=f) == wr).all(), f"frame {f} wta right"
+        exp = O.lr_check_range(O.median3x3(wl), O.median3x3(wr), ls[f], md)
+        assert (disp[f] == exp).all(), f"frame {f} disparity"
+    eng.close()
+
+
+PAIRS_CASES = [
+    # w, h, D, min_disp, frames
+    (173, 67, 64, 0, 1),      # ragged; 3 blocks of 64 columns
+    (200, 120, 128, 4, 3),    # 7 blocks of 32 columns
+    (330, 50, 256, 9, 2),     # 21 blocks of 16 columns
+    (64, 16, 64, 4, 1),       # one block: no hand-over at all
+    (257, 33, 128, 4, 9),     # last block holds a single valid column
+    (1242, 40, 128, 4, 2),    # full width: 39 blocks in the hand-over chain
+]
+
+
+@pytest.mark.parametrize("w,h,D,md,n", PAIRS_CASES)
+def test_pairs_plan_stage_by_stage(torch_cuda, w, h, D, md, n):
+    """Launch plan PAIRS: slab 0 / 1 must hold the penalty sums of {down, down-right} / {up, up-right}
+    (L_a + L_b - 2 C), slabs 2, 3, 5, 6 the plain path costs, and WTA maps and disparity must equal the oracle's."""
+    torch = torch_cuda
+    P = 8
+    eng = make_engine(w, h, D, P, md, inflight=max(n, 2), plan="pairs")
+    assert eng.describe_plan(n)["plan"] == "pairs"
+    ls, rs = synth.make_batch(n, w, h, D, md, seed=5000 + w)
+    disp = eng.compute_disparity(dev(torch, ls), dev(torch, rs)).cpu().numpy()
+    assert eng.device_status() == 0, "a pair sweep timed out on its neighbour"
+    for f in range(n):
+        cl, cr = O.census(ls[f]), O.census(rs[f])
+        C = O.aggregate_path(cl, cr, D, md, 0, 0, 0, 1).astype(np.int32)   # P1 = P2 = 0: the plain matching cost
+        L = [O.aggregate_path(cl, cr, D, md, 10, 120, *O.path_dir(i)) for i in range(P)]
+        assert O.path_dir(0) == (0, 1) and O.path_dir(4) == (1, 1) and O.path_dir(1) == (0, -1) and O.path_dir(7) == (1, -1)
+        for slab, (pa, pb) in ((0, (0, 4)), (1, (1, 7))):
+            exp = L[pa].astype(np.int32) + L[pb].astype(np.int32) - 2 * C
+            assert exp.min() >= 0 and exp.max() <= 240
+            got = eng.debug_read(16 + slab, frame_slot=f)
+            assert (got == exp).all(), f"frame {f} pair slab {slab}: {int((got != exp).sum())} cells differ, first at {np.argwhere(got != exp)[0]}"
+        for i in (2, 3, 5, 6):
+            assert (eng.debug_read(16 + i, frame_slot=f) == L[i]).all(), f"frame {f} path {i}"
+        S = sum(x.astype(np.uint16) for x in L)
+        wl, wr = O.wta(S, 12)
+        assert (eng.debug_read(32, frame_slot=f) == wl).all(), f"frame {f} wta left"
         assert (eng.debug_read(33, frame_slot=f) == wr).all(), f"frame {f} wta right"
         exp = O.lr_check_range(O.median3x3(wl), O.median3x3(wr), ls[f], md)
         assert (disp[f] == exp).all(), f"frame {f} disparity"
