@@ -125,6 +125,7 @@ def main():
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--allow-shared-gpu", action="store_true", help="rehearsals only: let ranks share a GPU when the box has fewer than --gpus")
+    ap.add_argument("--chunk", type=int, default=0, help="frames per launch sequence inside a batch (0 = engine default)")
     ap.add_argument("--plan", default="auto", choices=["auto", "slabs", "fused_up", "pairs"], help="force a launch plan of the SGM core (all bit-identical)")
     args = ap.parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -161,6 +162,8 @@ def main():
                  max_inflight=B if args.no_overlap else 2 * B, device_id=dev_index)
     if args.plan != "auto":
         eng.set_plan(args.plan)
+    if args.chunk:
+        eng.set_chunk_frames(args.chunk)
     plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
     pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=not args.no_overlap)
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM

@@ -357,28 +357,49 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
 // P windows of D right features overlap in all but P-1 entries.  Per-lane window loads cost 4 B per
 // DP cell through the L1->VGPR path (rocprofv3: TA_BUSY 76 %, TD_BUSY 78 %, 3x line-access inflation
 // from the 4-byte-aligned dwordx4 loads) and bound the first two versions of this kernel; instead the
-// wave loads the union window once, coalesced (NLD dwords per lane), writes it to a wave-private LDS
-// buffer and every lane reads its 16 features from there.  Window dword w lives at LDS slot
-// w + 4*(w>>4): the 4-dword pad per 16 makes the lanes' 16-dword stride conflict-free on the 32 banks.
+// wave loads the window once, coalesced, writes it to a wave-private LDS buffer and every lane reads
+// its 16 features from there.
+// Layout: one REGION per disparity chunk g (= lane gl of a pixel): the RL = 16 + P-1 window dwords the P pixels'
+// chunk-g lanes read, contiguous, so that a lane's 16 features sit at region base + pg + k -- one address register
+// and immediate offsets (the first layout padded every 16 dwords and needed P-1 extra address registers per lane,
+// 15 of them at D = 64, which cost that variant an occupancy step and 47 % of its LDS cycles in bank conflicts).
+// Regions start RS dwords apart with RS = P/2 (mod 32): the 32 lanes one ds_read_b32 cycle serves are P/2 pixels x
+// LPP chunks = LPP runs of P/2 consecutive dwords, which then tile the 32 banks exactly, for every k.
 template <int LPP>
 struct Win {
     static constexpr int P = 64 / LPP;              // pixels (scan lines) per wave
     static constexpr int D = 16 * LPP;
-    static constexpr int MAXW = D - 2 + P;          // last window dword that is ever read
-    static constexpr int SLOTS = MAXW + 4 * (MAXW >> 4) + 1;
-    static constexpr int NLD = (SLOTS + 63) / 64;   // cooperative dword loads per lane and step
-    static constexpr int BUF = NLD * 64;            // dwords per LDS buffer
-    static constexpr int KX = 16 - (P - 1);         // first k whose slot may sit behind one more pad
+    static constexpr int RL = 16 + P - 1;           // dwords per region
+    static constexpr int RS = LPP == 4 ? 40 : LPP == 8 ? 36 : 34;   // region stride: >= RL, = P/2 mod 32
+    static constexpr int NE = LPP * RL;             // staged dwords per step (window dwords shared by two regions are staged twice)
+    static constexpr int NLD = (NE + 63) / 64;      // cooperative dword loads per lane and step
+    static constexpr int BUF = LPP * RS;            // dwords per LDS buffer
+    static_assert(RS >= RL && RS % 32 == (P / 2) % 32, "region stride");
+};
+
+// per-lane constants of the staging: where the lane's i-th cooperative load comes from / goes to, and where it reads
+template <int LPP>
+struct WinLane {
+    unsigned goff[Win<LPP>::NLD];   // byte offset from the window's first dword (window dword 0 = disparity D-1 of the wave's first pixel)
+    int lslot[Win<LPP>::NLD];       // LDS dword index inside the buffer
+    int rbase;                      // LDS dword index of this lane's feature 0
+    __device__ __forceinline__ void init(int lane) {
+        using WN = Win<LPP>;
+#pragma unroll
+        for (int i = 0; i < WN::NLD; ++i) {
+            const int e = min(64 * i + lane, WN::NE - 1);   // the last round's excess lanes repeat the last element
+            const int g = e / WN::RL, o = e - g * WN::RL;
+            goff[i] = (unsigned)(WN::D - 16 - 16 * g + o) * 4u;
+            lslot[i] = g * WN::RS + o;
+        }
+        rbase = (lane % LPP) * WN::RS + lane / LPP;
+    }
 };
 
 template <int LPP>
-__device__ __forceinline__ void win_read(const uint32_t *lds_buf, int base_slot, const int (&xslot)[Win<LPP>::P - 1],
-                                         uint32_t (&r)[16]) {
+__device__ __forceinline__ void win_read(const uint32_t *lds_buf, int rbase, uint32_t (&r)[16]) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (k < Win<LPP>::KX) r[k] = lds_buf[base_slot + k];
-        else r[k] = lds_buf[xslot[k - Win<LPP>::KX]];
-    }
+    for (int k = 0; k < 16; ++k) r[k] = lds_buf[rbase + k];
 }
 
 // 6 waves per SIMD (<= 80 VGPRs) fit without spills for D >= 128; the D = 64 variant carries 15 lane offsets more
@@ -424,6 +445,18 @@ __device__ __forceinline__ void hscan_sliding(uint32_t (&st)[8], uint32_t &mm, c
     for (int gi = 1; gi < groups; ++gi) group();
 }
 
+// prefetch depth of the vertical / diagonal scans in steps (see the note at the loop)
+#ifndef CART_VDEPTH4
+#define CART_VDEPTH4 4
+#endif
+#ifndef CART_VDEPTH8
+#define CART_VDEPTH8 2
+#endif
+#ifndef CART_VDEPTH16
+#define CART_VDEPTH16 2
+#endif
+template <int LPP> constexpr int v_depth() { return LPP == 4 ? CART_VDEPTH4 : LPP == 8 ? CART_VDEPTH8 : CART_VDEPTH16; }
+
 #ifndef CART_AGG_WAVES
 #define CART_AGG_WAVES 4
 #endif
@@ -435,6 +468,9 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     constexpr int LINES_PER_BLOCK = kAggWaves * P;
     __shared__ uint32_t s_win[kAggWaves][2][WN::BUF];
     const Geometry &g = a.g;
+#if defined(CART_EXPERIMENTS) && defined(CART_ALLPRIO)
+    __builtin_amdgcn_s_setprio(CART_ALLPRIO);
+#endif
     // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
     // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
     int di = 0;
@@ -471,7 +507,10 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     if (dy == 0) {
         // ---- horizontal scans: the wave's pixels sit on P different rows, nothing to share; per-lane loads.
         // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
-        __builtin_amdgcn_s_setprio(3);
+#ifndef CART_HPRIO
+#define CART_HPRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(CART_HPRIO);
         if (line >= nlines) return;
         const int y0r = a.dirs[di].jmin + line0;          // row of the wave's first line (uniform)
         const int x = dx > 0 ? 0 : g.w - 1, t1 = g.w;
@@ -518,38 +557,35 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     }
 
     // ---- vertical / diagonal scans: lines are indexed by their (skewed) entry column j
-    const int j = a.dirs[di].jmin + line;
+    // A wave that holds fewer than P lines (the last one of a direction: 1242 columns = 77 x 16 + 10 at D = 64,
+    // 155 x 8 + 2 at D = 128) lets its surplus lane groups CLONE its last valid line: same reads, same arithmetic, the
+    // same bytes stored to the same cells.  (Sending such waves through the synchronous ragged path instead made one wave
+    // per frame and direction walk all its steps at memory latency -- 0.26 ms on an idle GPU, ~0.6 ms under load, which
+    // was the whole launch time at D = 64 / 4 paths.)
+    const int nv = min(P, nlines - line0);  // valid lines in this wave (wave-uniform)
+    const int pgv = min(pg, nv - 1);        // the line of the wave this lane group works on
+    const int j = a.dirs[di].jmin + line0 + pgv;
     const int ys = dy > 0 ? 0 : g.h - 1;
     int t0, t1;  // this lane group's active steps
     if (dx > 0) { t0 = max(0, -j); t1 = min(g.h, g.w - j); }
     else if (dx < 0) { t0 = max(0, j - g.w + 1); t1 = min(g.h, j + 1); }
     else { t0 = 0; t1 = g.h; }
-    const bool valid_line = line < nlines;
-    if (!valid_line) { t0 = 0; t1 = 0; }
     // wave-uniform ranges: [tb, te) = union of the wave's (adjacent) lines, [tm0, tm1) = steps on which
-    // every lane group of the wave is active (empty when the wave holds lines past the last one)
-    const int nv = min(P, nlines - line0);  // valid lines in this wave
+    // every lane group of the wave is active
     const int jf = a.dirs[di].jmin + line0, jl = jf + nv - 1;
     int tb, te, tm0, tm1;
     if (dx > 0) { tb = max(0, -jl); te = min(g.h, g.w - jf); tm0 = max(0, -jf); tm1 = min(g.h, g.w - jl); }
     else if (dx < 0) { tb = max(0, jf - g.w + 1); te = min(g.h, jl + 1); tm0 = max(0, jl - g.w + 1); tm1 = min(g.h, jf + 1); }
     else { tb = 0; te = g.h; tm0 = 0; tm1 = g.h; }
     if (tb >= te) return;
-    if (nv < P || tm0 >= tm1) { tm0 = te; tm1 = te; }  // everything through the ragged path
+    if (tm0 >= tm1) { tm0 = te; tm1 = te; }  // no step with every line active: everything through the ragged path
 
-    // cooperative window load: LDS slot l = 64*i + lane  <-  window dword 16*(l/20) + min(l%20, 15)
-    unsigned goff[WN::NLD];
-#pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) {
-        const int l = 64 * i + lane;
-        goff[i] = (unsigned)(16 * (l / 20) + min(l % 20, 15)) * 4u;  // bytes
-    }
-    // this lane's 16 features: window dwords wl .. wl+15, wl = pg + D-16 - 16*gl
-    const int wl = pg + WN::D - 16 - d0;
-    const int base_slot = wl + 4 * (wl >> 4);
-    int xslot[P - 1];
-#pragma unroll
-    for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
+    // cooperative window load + this lane's 16 features (window dwords pg + D-16 - 16*gl + k), see Win / WinLane
+    WinLane<LPP> wlane;
+    wlane.init(lane);
+    unsigned (&goff)[WN::NLD] = wlane.goff;
+    const int (&lslot)[WN::NLD] = wlane.lslot;
+    const int rbase = gl * WN::RS + pgv;
     uint32_t *buf0 = &s_win[wid][0][0], *buf1 = &s_win[wid][1][0];
 
     // pointers as a function of the step t
@@ -560,18 +596,18 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     const uint32_t *pw_base = a.cen_r + uniform(cen_off - g.min_disp - (WN::D - 1));  // window start at t = 0
     const uint32_t *pl_u = a.cen_l + uniform(cen_off);
     uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + jf) * g.D);
-    unsigned lo_l = (unsigned)pg * 4u, lo_o = (unsigned)(pg * WN::D + d0);  // bytes
+    unsigned lo_l = (unsigned)pgv * 4u, lo_o = (unsigned)(pgv * WN::D + d0);  // bytes
 
     // ragged start / end of diagonal lines (and waves with invalid lines): simple, fully synchronous steps
     auto ragged = [&](int ta, int tz) {
         for (int t = ta; t < tz; ++t) {
             const uint32_t *pw = pw_base + t * cstride;
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = ld_u32(pw, goff[i]);
+            for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = ld_u32(pw, goff[i]);
             if (t >= t0 && t < t1) {
                 uint32_t xr[16];
                 ca.fl = ld_u32(pl_u + t * cstride, lo_l);
-                win_read<LPP>(buf0, base_slot, xslot, ca.r);
+                win_read<LPP>(buf0, rbase, ca.r);
                 agg_xor(ca, xr);
                 agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po_u + t * ostride) + pin_v(lo_o));
             }
@@ -581,45 +617,76 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     if (tm0 < tm1) {
         const uint32_t *pw = pw_base + tm0 * cstride, *pl = pl_u + tm0 * cstride;
         uint8_t *po = po_u + tm0 * ostride;
-        uint32_t g0[WN::NLD], g1[WN::NLD], f0, f1;
+        // K register sets of prefetched windows: the loads of step t+K are issued at the start of step t.  vmcnt retires in
+        // issue order and counts stores, so the loads consumed at step t wait for the slab stores issued up to step t-K:
+        // with K = 2 every step of a wave sat out the acknowledgement of a two-step-old store (~2 us under write pressure,
+        // i.e. ~1 us per step however few waves shared the SIMD) -- invisible at D = 128 / 8 paths, where enough waves per
+        // SIMD cover it, but 0.4 ms per launch at D = 64 / 4 paths, whose vertical waves finish last on their own.
+        constexpr int K = v_depth<LPP>();
+        static_assert(K % 2 == 0 && K >= 2, "the LDS window buffers alternate");
+        uint32_t gs[K][WN::NLD], fs[K];
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = ld_u32(pw, goff[i]);
-        f0 = ld_u32(pl, lo_l);
+        for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = ld_u32(pw, goff[i]);   // step tm0 straight into its LDS buffer
+        fs[0] = ld_u32(pl, lo_l);
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + cstride, goff[i]);  // step tm0+1
-        f1 = ld_u32(pl + cstride, lo_l);
+        for (int j = 1; j < K; ++j) {
+#pragma unroll
+            for (int i = 0; i < WN::NLD; ++i) gs[j][i] = ld_u32(pw + j * cstride, goff[i]);
+            fs[j] = ld_u32(pl + j * cstride, lo_l);
+        }
         uint32_t xr[16];
         int t = tm0;
-        for (; t + 1 < tm1; t += 2) {
+        // sub-step J of a K-step trip: buffer J&1 holds the window of step t+J, fs[J] its left feature, set J is free
+#if !defined(CART_EXPERIMENTS) || !defined(CART_AGG_ABLATE)
+#undef CART_AGG_ABLATE
+#define CART_AGG_ABLATE 0   // -DCART_EXPERIMENTS -DCART_AGG_ABLATE=mask, timing experiments only (results are wrong): 1 no LDS window read, 2 no LDS window write, 4 no global loads in the loop
+#endif
+        auto sub = [&](auto jc, auto reload) {
+            constexpr int J = decltype(jc)::value;
+            uint32_t *cur = (J & 1) ? buf1 : buf0, *nxt = (J & 1) ? buf0 : buf1;
+            ca.fl = fs[J];
+            if constexpr (decltype(reload)::value && !(CART_AGG_ABLATE & 4)) {
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) g0[i] = ld_u32(pw + 2 * cstride, goff[i]);  // step t+2, issued before this step's store
-            ca.fl = f0;
-            f0 = ld_u32(pl + 2 * cstride, lo_l);
+                for (int i = 0; i < WN::NLD; ++i) gs[J][i] = ld_u32(pw + (J + K) * cstride, goff[i]);  // step t+J+K, issued before this step's store
+                fs[J] = ld_u32(pl + (J + K) * cstride, lo_l);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            win_read<LPP>(buf0, base_slot, xslot, ca.r);
+            if constexpr (CART_AGG_ABLATE & 1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ca.r[k] = gs[J][k % WN::NLD] + (uint32_t)k * st[k & 7];
+            } else {
+                win_read<LPP>(cur, rbase, ca.r);
+            }
             agg_xor(ca, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
+            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + J * ostride) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(CART_AGG_ABLATE & 2)) {
 #pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = g1[i];        // window of step t+1
-#pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + 3 * cstride, goff[i]);  // step t+3
-            cb.fl = f1;
-            f1 = ld_u32(pl + 3 * cstride, lo_l);
-            __builtin_amdgcn_sched_barrier(0);
-            win_read<LPP>(buf1, base_slot, xslot, cb.r);
-            agg_xor(cb, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + ostride) + pin_v(lo_o));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = g0[i];        // window of step t+2
-            pw += 2 * cstride; pl += 2 * cstride; po += 2 * ostride;
+                for (int i = 0; i < WN::NLD; ++i) nxt[lslot[i]] = gs[(J + 1) % K][i];   // window of step t+J+1
+            }
+        };
+        for (; t + K <= tm1; t += K) {
+            sub(std::integral_constant<int, 0>{}, std::true_type{});
+            sub(std::integral_constant<int, 1>{}, std::true_type{});
+            if constexpr (K > 2) {
+                sub(std::integral_constant<int, 2>{}, std::true_type{});
+                sub(std::integral_constant<int, 3>{}, std::true_type{});
+            }
+            if constexpr (K > 4) {
+                sub(std::integral_constant<int, 4>{}, std::true_type{});
+                sub(std::integral_constant<int, 5>{}, std::true_type{});
+            }
+            pw += K * cstride; pl += K * cstride; po += K * ostride;
         }
-        if (t < tm1) {
-            ca.fl = f0;
-            win_read<LPP>(buf0, base_slot, xslot, ca.r);
-            agg_xor(ca, xr);
-            agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po) + pin_v(lo_o));
+        // the last tm1 - t < K steps: their windows are already in flight
+        if (t < tm1) sub(std::integral_constant<int, 0>{}, std::false_type{});
+        if (t + 1 < tm1) sub(std::integral_constant<int, 1>{}, std::false_type{});
+        if constexpr (K > 2) {
+            if (t + 2 < tm1) sub(std::integral_constant<int, 2>{}, std::false_type{});
+        }
+        if constexpr (K > 4) {
+            if (t + 3 < tm1) sub(std::integral_constant<int, 3>{}, std::false_type{});
+            if (t + 4 < tm1) sub(std::integral_constant<int, 4>{}, std::false_type{});
         }
     }
     ragged(tm1, te);
@@ -789,17 +856,11 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
     const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
 
-    unsigned goff[WN::NLD];
-#pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) {
-        const int l = 64 * i + lane;
-        goff[i] = (unsigned)(16 * (l / 20) + min(l % 20, 15)) * 4u;
-    }
-    const int wl = pg + D - 16 - d0;
-    const int base_slot = wl + 4 * (wl >> 4);
-    int xslot[P - 1];
-#pragma unroll
-    for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
+    WinLane<LPP> wlane;
+    wlane.init(lane);
+    unsigned (&goff)[WN::NLD] = wlane.goff;
+    const int (&lslot)[WN::NLD] = wlane.lslot;
+    const int rbase = wlane.rbase;
     uint32_t *buf0 = &s_win[wid][0][0], *buf1 = &s_win[wid][1][0];
 
     const ptrdiff_t cstride = (ptrdiff_t)DY * g.cpitch;
@@ -821,7 +882,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     auto step = [&](int t, const uint32_t *wbuf, uint32_t fl, CART_GLOBAL uint8_t *dst) {
         CensusRegs c;
         c.fl = fl;
-        win_read<LPP>(wbuf, base_slot, xslot, c.r);
+        win_read<LPP>(wbuf, rbase, c.r);
         uint32_t cost[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -851,7 +912,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     // software pipeline as in aggregate_kernel: the loads of step t+2 are issued before the store of step t
     uint32_t g0[WN::NLD], g1[WN::NLD], f0, f1;
 #pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = ld_u32(pw, goff[i]);
+    for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = ld_u32(pw, goff[i]);
     f0 = ld_u32(pl, lo_l);
 #pragma unroll
     for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + cstride, goff[i]);
@@ -866,7 +927,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
         step(t, buf0, fa, sgpr(po) + pin_v(lo_o));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf1[64 * i + lane] = g1[i];
+        for (int i = 0; i < WN::NLD; ++i) buf1[lslot[i]] = g1[i];
 #pragma unroll
         for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + 3 * cstride, goff[i]);
         const uint32_t fb = f1;
@@ -875,7 +936,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
         step(t + 1, buf1, fb, sgpr(po + ostride) + pin_v(lo_o));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf0[64 * i + lane] = g0[i];
+        for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = g0[i];
         pw += 2 * cstride; pl += 2 * cstride; po += 2 * ostride;
     }
     if (t < g.h) step(t, buf0, f0, sgpr(po) + pin_v(lo_o));
@@ -982,7 +1043,13 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     const float uniq = a.uniq;
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
     const int grp = threadIdx.x / LPP, gl = threadIdx.x % LPP, d0 = gl * 16;
+    // Right view: every lane min-reduces its 16 (S << 16 | d) keys into the tile's array indexed by p = x - d (ds_min_u32),
+    // slot p - (x0 - (D-1)).  (Walking the tile's diagonals per right pixel instead -- 64 dependent LDS reads on 127 of
+    // the 256 threads at D = 64 -- was over half of this kernel's VALU instructions and made the D = 64 variant VALU-bound.)
+    __shared__ uint32_t s_rv[kWtaTileX + D];
+    for (int i = threadIdx.x; i < kWtaTileX + D; i += 256) s_rv[i] = 0xffffffffu;
     __shared__ uint32_t s_cen[PAIRS ? kWtaTileX + D : 1];   // right features of columns x0 - min_disp - (D-1) .. x0 + 63 - min_disp
+    if constexpr (!PAIRS) __syncthreads();
     if constexpr (PAIRS) {
         const uint32_t *crow = a.cen_r + (size_t)frame * g.census_elems + (size_t)y * g.cpitch + g.cpadl + x0 - g.min_disp - (D - 1);
         for (int i = threadIdx.x; i < kWtaTileX + D - 1; i += 256) s_cen[i] = crow[i];   // left of the image: zero padding (oracle S3)
@@ -1024,6 +1091,15 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * DP + d0);  // LDS tile in natural disparity order
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
         dst[1] = v4u{sm[4], sm[5], sm[6], sm[7]};
+        if (x0 + xl < g.w) {   // columns past the image (clamped duplicates of the last one) have no right view
+            uint32_t *rm = &s_rv[xl + D - 1 - d0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);   // local disparity of the low half of sm[q]
+                atomicMin(rm - da, (sm[q] << 16) | (uint32_t)(d0 + da));
+                atomicMin(rm - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+            }
+        }
         // packed argmin keys: S*16 + local disparity index
         uint32_t key[8];
 #pragma unroll
@@ -1068,22 +1144,11 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         }
     }
 
-    // right view (oracle S6): partial minima over this tile's pixels, merged by atomicMin
+    // right view (oracle S6): the tile's minima per right pixel are complete in s_rv, merged across tiles by atomicMin
     for (int pi = threadIdx.x; pi < kWtaTileX + D - 1; pi += 256) {
         const int p = x0 - (D - 1) + pi;
-        if (p < 0 || p >= g.w) continue;
-        const int xa = max(x0, p), xb = min(min(x0 + kWtaTileX, p + D), g.w);
-        uint32_t best = 0xffffffffu;
-        int x = xa;
-        const uint16_t *sp = s_lds + (x - x0) * DP + (x - p);
-        for (; x + 3 < xb; x += 4, sp += 4 * (DP + 1)) {
-            const uint32_t d = (uint32_t)(x - p);
-            const uint32_t k0 = ((uint32_t)sp[0] << 16) | d, k1 = ((uint32_t)sp[DP + 1] << 16) | (d + 1);
-            const uint32_t k2 = ((uint32_t)sp[2 * (DP + 1)] << 16) | (d + 2), k3 = ((uint32_t)sp[3 * (DP + 1)] << 16) | (d + 3);
-            best = min(min(best, min(k0, k1)), min(k2, k3));
-        }
-        for (; x < xb; ++x, sp += DP + 1) best = min(best, ((uint32_t)sp[0] << 16) | (uint32_t)(x - p));
-        if (xa < xb) atomicMin(&right_pk[(size_t)frame * g.npx + (size_t)y * g.w + p], best);
+        const uint32_t best = s_rv[pi];
+        if (p >= 0 && p < g.w && best != 0xffffffffu) atomicMin(&right_pk[(size_t)frame * g.npx + (size_t)y * g.w + p], best);
     }
 }
 
@@ -1187,17 +1252,11 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     for (int i = threadIdx.x; i < 2048; i += NT) s_thr[i] = (uint16_t)uniq_threshold((uint32_t)i, a.uniq);
 
     // right-census window of the wave (see aggregate_kernel): cooperative load offsets + this lane's read slots
-    unsigned goff[WN::NLD];
-#pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) {
-        const int l = 64 * i + lane;
-        goff[i] = (unsigned)(16 * (l / 20) + min(l % 20, 15)) * 4u;
-    }
-    const int wl = pg + D - 16 - d0;
-    const int base_slot = wl + 4 * (wl >> 4);
-    int xslot[P - 1];
-#pragma unroll
-    for (int k = WN::KX; k < 16; ++k) xslot[k - WN::KX] = (wl + k) + 4 * ((wl + k) >> 4);
+    WinLane<LPP> wlane;
+    wlane.init(lane);
+    unsigned (&goff)[WN::NLD] = wlane.goff;
+    const int (&lslot)[WN::NLD] = wlane.lslot;
+    const int rbase = wlane.rbase;
     uint32_t *wbuf = &s_win[wid][0];
 
     // row-0 bases (wave-uniform, kept in SGPRs) + constant per-lane byte offsets: every load is "scalar base + VGPR
@@ -1247,10 +1306,10 @@ __global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(Fus
     auto agg = [&](int y) {   // census registers hold row y; they are re-loaded for row y-1 once consumed
         if (CART_FUSED_ABLATE & 1024) return;   // timing experiment: no census loads, no window staging, no recurrence
 #pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) wbuf[64 * i + lane] = r.win[i];
+        for (int i = 0; i < WN::NLD; ++i) wbuf[lslot[i]] = r.win[i];
         CensusRegs c;
         c.fl = r.fl;
-        win_read<LPP>(wbuf, base_slot, xslot, c.r);
+        win_read<LPP>(wbuf, rbase, c.r);
         uint32_t xr[16];
         agg_xor(c, xr);
         load_census_row(max(y - 1, 0));

@@ -6,6 +6,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); PKG=$ROOT/cart-slam_amd; name=$1; shift
 OUT=$PKG/build/ab/$name; mkdir -p $OUT
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I$ROOT/include -I$PKG/csrc -DCART_EXPERIMENTS "$@" -c $PKG/csrc/sgm_kernels.hip -o $OUT/sgm_kernels.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libcart_engine.so $OUT/sgm_kernels.o $PKG/build/cart_engine.o $PKG/build/post_kernels.o $PKG/build/flow_kernels.o $PKG/build/superpixel_kernels.o
-rm -f $OUT/sgm_kernels.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I$ROOT/include -I$PKG/csrc -DCART_EXPERIMENTS "$@" -c $PKG/csrc/cart_engine.hip -o $OUT/cart_engine.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libcart_engine.so $OUT/sgm_kernels.o $OUT/cart_engine.o $PKG/build/post_kernels.o $PKG/build/flow_kernels.o $PKG/build/superpixel_kernels.o
+rm -f $OUT/sgm_kernels.o $OUT/cart_engine.o
 echo built $OUT/libcart_engine.so
