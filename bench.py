@@ -41,49 +41,71 @@ def alg_bytes_wta(w, h, D, P):
     return w * h * (P * D + 4)
 
 
+CPU_BASELINE_CHILD = r"""
+import json, os, sys, time
+root, w, h, D, P, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+sys.path[:0] = [os.path.join(root, "cart-slam_amd"), os.path.join(root, "tests")]
+import numpy as np
+import oracle_lib as O      # cpu_baseline leg: allowed importer of oracle/
+from cartslam import synth
+O.build()
+l, r, _ = synth.make_pair(w, h, D, 4)
+def one():
+    d = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+    dd, hist = O.plane_derivative(d)
+    ok, pp = O.histogram_peak_params(hist)
+    pl = O.classify(dd, pp)
+    O.ccl(pl)
+one(); one()      # warm-up: page faults, thread pool
+times, t_all = [], time.perf_counter()
+while len(times) < 3 or (time.perf_counter() - t_all < budget and len(times) < 40):
+    t0 = time.perf_counter(); one(); times.append(time.perf_counter() - t0)
+times.sort()
+print(json.dumps({"median_s": times[len(times) // 2], "min_s": times[0], "max_s": times[-1], "reps": len(times)}))
+"""
+
+
 def cpu_baseline(w, h, D, P, seconds_budget=12.0):
-    """Times the CPU oracle (the 'port': oracle/cart_oracle.c, OpenMP) on this box's host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import oracle_lib as O  # cpu_baseline leg: allowed importer of oracle/
-    from cartslam import synth
-    cores = os.cpu_count() or 1
+    """Times the CPU oracle (the 'port': oracle/cart_oracle.c, OpenMP) on this box's host cores: a child process with no
+    torch / GPU in it, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: both have to be set before libgomp
+    loads), median over >= 3 whole-pair repetitions, spread reported."""
+    import math
+    import subprocess
+    visible = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    O.build()
-    l, r, _ = synth.make_pair(w, h, D, 4)
-
-    def one():
-        d = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
-        dd, hist = O.plane_derivative(d)
-        ok, pp = O.histogram_peak_params(hist)
-        pl = O.classify(dd, pp)
-        O.ccl(pl)
-
-    one()  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(); n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget:
+    cores = visible
+    # a container usually sees every host CPU but may run only a share of them (cgroup CPU quota): more threads than
+    # that share only fight over it (256 pinned threads on a 16-CPU share ran 4-10x slower than 16, and 4x apart)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            quota = float(txt[0]) if txt[0] != "max" else -1.0
+            period = float(txt[1]) if len(txt) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cores = max(1, min(visible, int(math.ceil(quota / period))))
             break
-    out = {"value": round(n / el, 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
-           "sample": f"{n} pair(s) {w}x{h} D={D} {P} paths + plane labelling + CCL, OpenMP oracle, {el:.1f} s"}
-    try:  # secondary, BASELINE.md section 4: only if OpenCV happens to be installed (a DIFFERENT algorithm: timing only)
-        import cv2
-        sgbm = cv2.StereoSGBM_create(minDisparity=4, numDisparities=D, blockSize=3, uniquenessRatio=12,
-                                     mode=cv2.STEREO_SGBM_MODE_HH if P == 8 else cv2.STEREO_SGBM_MODE_SGBM)
-        sgbm.compute(l, r)
-        t0 = time.perf_counter(); k = 0
-        while time.perf_counter() - t0 < 5.0:
-            sgbm.compute(l, r); k += 1
-        out["opencv_sgbm_pairs_per_s"] = round(k / (time.perf_counter() - t0), 3)
-    except Exception:
-        pass
-    return out
+        except Exception:
+            continue
+    pinned = cores == visible   # pin only when the threads have the cores to themselves
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_DYNAMIC="false", OMP_PROC_BIND="close" if pinned else "false")
+    if pinned:
+        env["OMP_PLACES"] = "cores"
+    else:
+        env.pop("OMP_PLACES", None)
+    r = subprocess.run([sys.executable, "-c", CPU_BASELINE_CHILD, ROOT, str(w), str(h), str(D), str(P), str(seconds_budget)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("cpu_baseline child failed: " + r.stderr[-2000:])
+    t = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": round(1.0 / t["median_s"], 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
+            "spread": {"fastest": round(1.0 / t["min_s"], 4), "slowest": round(1.0 / t["max_s"], 4), "repetitions": t["reps"]},
+            "sample": f"median of {t['reps']} repetitions of 1 pair {w}x{h} D={D} {P} paths + plane labelling + CCL; OpenMP oracle "
+                      f"(census, paths, WTA, medians, LR check, interpolation, 5-tap mean, classify run on all {cores} threads; "
+                      "the histogram pass, the peak finder and the CCL union-find are serial), " +
+                      ("threads pinned close/cores" if pinned else f"{cores} threads = the container's CPU share of {visible} visible CPUs, not pinned")}
 
 
 def launch_ranks(args):
@@ -125,6 +147,8 @@ def main():
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--allow-shared-gpu", action="store_true", help="rehearsals only: let ranks share a GPU when the box has fewer than --gpus")
+    ap.add_argument("--pcie-copy", default="narrow", choices=["narrow", "blit"], help="how the PCIe-inclusive leg downloads its outputs")
+    ap.add_argument("--pcie-wgs", type=int, default=8, help="workgroups of the narrow download kernel")
     ap.add_argument("--chunk", type=int, default=0, help="frames per launch sequence inside a batch (0 = engine default)")
     ap.add_argument("--plan", default="auto", choices=["auto", "slabs", "fused_up", "pairs"], help="force a launch plan of the SGM core (all bit-identical)")
     args = ap.parse_args()
@@ -217,30 +241,40 @@ def main():
         h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
         bufs = [(torch.empty_like(left), torch.empty_like(right)) for _ in range(3)]
         consumed = [None] * 3
-        def pcie_step(i):
+        uploaded = {}
+        def upload(i):   # pinned host -> HBM on the copy stream (SDMA), one step AHEAD of the batch that consumes it
             dl, dr = bufs[i % 3]
             if consumed[i % 3] is not None:
                 h2d.wait_event(consumed[i % 3])  # the batch that last read this input buffer has finished its disparity
             with torch.cuda.stream(h2d):
                 dl.copy_(hl, non_blocking=True); dr.copy_(hr, non_blocking=True)
-                up = h2d.record_event()
-            torch.cuda.current_stream().wait_event(up)
+                uploaded[i] = h2d.record_event()
+        def pcie_step(i):
+            dl, dr = bufs[i % 3]
+            if i not in uploaded:
+                upload(i)
+            upload(i + 1)
+            torch.cuda.current_stream().wait_event(uploaded.pop(i))
             o = pipe.process_batch(dl, dr)
             consumed[i % 3] = torch.cuda.current_stream().record_event()
             d2h.wait_event(o["done"]) if "done" in o else d2h.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(d2h):
-                hd.copy_(o["disparity"], non_blocking=True); hp.copy_(o["planes"], non_blocking=True)
+                if args.pcie_copy == "narrow":   # a few workgroups write straight into the pinned (device-mapped) host buffers
+                    eng.copy_narrow(hd, o["disparity"], args.pcie_wgs); eng.copy_narrow(hp, o["planes"], args.pcie_wgs)
+                else:                            # hipMemcpyAsync: a full-width blit kernel on this system
+                    hd.copy_(o["disparity"], non_blocking=True); hp.copy_(o["planes"], non_blocking=True)
                 o["disparity"].record_stream(d2h); o["planes"].record_stream(d2h)
         for i in range(2):
             pcie_step(i)
         torch.cuda.synchronize()
         tp = time.perf_counter()
         n_pcie = max(4, min(args.steps, 20))
-        for i in range(n_pcie):
+        for i in range(2, 2 + n_pcie):
             pcie_step(i)
         torch.cuda.synchronize()
         pcie = {"pairs_per_s": round(B * n_pcie / (time.perf_counter() - tp), 1), "steps": n_pcie,
-                "moved_per_pair": "2 x gray H2D (pinned), s16 disparity + u8 planes D2H"}
+                "moved_per_pair": "2 x gray H2D (pinned), s16 disparity + u8 planes D2H",
+                "download": "cart_copy_narrow (8 workgroups) into pinned host memory" if args.pcie_copy == "narrow" else "hipMemcpyAsync"}
     seq = None
     if args.sequence:
         # Informational (never `value`): BASELINE configs[4].  64 frames when they divide over the ranks and fit a batch.
@@ -324,6 +358,7 @@ def main():
                                    "traffic": wt, "alg_bytes_per_launch": wta_bytes, "launch_ms": round(wta_ms, 4)}
         if pcie:
             out["pcie_inclusive"] = pcie
+            out["value_pcie_inclusive"] = pcie["pairs_per_s"]   # the same step with the pair uploaded and disparity + planes downloaded
         if seq:
             out["sequence_mode"] = seq
         if world == 1 and not args.no_cpu_baseline:

@@ -94,6 +94,18 @@ class Engine:
         return {"frames_per_launch": lp.frames_per_launch, "plan": {0: "slabs", 1: "fused_up", 2: "pairs"}[lp.plan],
                 "slabs_written": lp.slabs_written}
 
+    def copy_narrow(self, dst, src, workgroups=0):
+        """dst <- src (same byte size, contiguous; dst may be a PINNED host tensor: its memory is mapped into the device's
+        address space) by a copy kernel of a few workgroups on the current stream (cart_copy_narrow)."""
+        nbytes = src.numel() * src.element_size()
+        if dst.numel() * dst.element_size() != nbytes or not dst.is_contiguous() or not src.is_contiguous():
+            raise EngineError("copy_narrow needs two contiguous tensors of the same byte size")
+        if not (dst.is_cuda or dst.is_pinned()) or not (src.is_cuda or src.is_pinned()):
+            raise EngineError("copy_narrow needs device tensors or pinned host tensors")
+        self._check(self._lib.cart_copy_narrow(self._h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, int(workgroups),
+                                               _stream_ptr()), "cart_copy_narrow")
+        return dst
+
     def device_status(self):
         """Synchronises; 0 = healthy (bit 0: a pair sweep timed out waiting for its neighbour block)."""
         st = C.c_uint(0)

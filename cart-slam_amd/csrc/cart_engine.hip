@@ -1160,6 +1160,18 @@ int cart_optical_flow(cart_engine *e, const uint8_t *cur, size_t cur_step, const
     return 0;
 }
 
+int cart_copy_narrow(cart_engine *e, void *dst, const void *src, size_t bytes, int workgroups, void *stream_) {
+    if (!e) return fail("engine is NULL");
+    if (!dst || !src) return fail("NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return fail("buffers must be 16-byte aligned");
+    if (workgroups < 0 || workgroups > 1024) return fail("workgroups must be in [0, 1024]");
+    if (bytes == 0) return 0;
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    launch_narrow_copy(src, dst, bytes, workgroups ? workgroups : 8, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- host-side peak finder (replaces src/utils/peaks.cpp:12-72 and planeseg.cu:405-458) ----
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right) {
     if (!data || n <= 0 || !born || !died || !left || !right) return fail("bad arguments");

@@ -754,6 +754,29 @@ void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int
                        (const int32_t *)slot, table, max_components, w, h, npx);
 }
 
-int kernel_count() { return 42; }  // sgm_kernels 15 (census, aggregate x3, wta x3, wta_fused x6, rv_merge, post) + post_kernels 16 + superpixel_kernels 8 + flow 3
+// ------------------------------------------------------------------ narrow copy (downloads over PCIe)
+// A device -> host-mapped copy for the module outputs a caller wants in host memory.  hipMemcpyAsync(D2H) runs here as
+// a full-width blit kernel whose waves sit on PCIe-latency stores all over the chip: with two of them per step next to the
+// compute kernels, the WTA launch went from 1.27 to 2.2 ms.  This one uses `blocks` workgroups only (PCIe Gen5 x16 needs
+// ~100 KB in flight; 8 x 256 lanes x 16 B x 4 deep = 128 KB) and leaves the other CUs alone.
+__global__ __launch_bounds__(256) void narrow_copy_kernel(const uint8_t *src, uint8_t *dst, size_t bytes) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * 256;
+    const v4u *s16 = reinterpret_cast<const v4u *>(src);
+    v4u *d16 = reinterpret_cast<v4u *>(dst);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte moves in flight per lane
+        const v4u a = __builtin_nontemporal_load(s16 + i), b = __builtin_nontemporal_load(s16 + i + stride);
+        const v4u c = __builtin_nontemporal_load(s16 + i + 2 * stride), d = __builtin_nontemporal_load(s16 + i + 3 * stride);
+        d16[i] = a; d16[i + stride] = b; d16[i + 2 * stride] = c; d16[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) d16[i] = __builtin_nontemporal_load(s16 + i);
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) dst[n16 * 16 + threadIdx.x] = src[n16 * 16 + threadIdx.x];
+}
+void launch_narrow_copy(const void *src, void *dst, size_t bytes, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(narrow_copy_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), bytes);
+}
+
+int kernel_count() { return 54; }  // sgm_kernels 26 (census, aggregate x3, pair_sweep x6, wta x6, wta_fused x6, rv_merge, post, uniq_table, +1) + post_kernels 17 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

@@ -1,4 +1,5 @@
 // modules.cpp -- the three hot-path modules on top of the C ABI (include/cart_engine.h).
+#include <exception>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
@@ -54,8 +55,15 @@ class StreamPool {
 struct ScopedStream {
     hipStream_t s = nullptr;
     const bool bulk;
-    explicit ScopedStream(bool bulk = false) : s(StreamPool::instance().acquire(bulk)), bulk(bulk) {}
-    ~ScopedStream() { if (s) StreamPool::instance().release(s, bulk); }
+    explicit ScopedStream(bool bulk = false) : s(StreamPool::instance().acquire(bulk)), bulk(bulk), exceptionsAtEntry(std::uncaught_exceptions()) {}
+    ~ScopedStream() {
+        if (!s) return;
+        // leaving through an exception with kernels still queued: drain them before the stream goes back to the pool and
+        // before the images they touch (declared earlier, destroyed later) go back to theirs
+        if (std::uncaught_exceptions() > exceptionsAtEntry) (void)hipStreamSynchronize(s);
+        StreamPool::instance().release(s, bulk);
+    }
+    const int exceptionsAtEntry;
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 

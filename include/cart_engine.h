@@ -298,6 +298,13 @@ int cart_superpixel_plane_classify(cart_engine *engine, const int16_t *deriv2, s
 int cart_optical_flow(cart_engine *engine, const uint8_t *cur, size_t cur_step, const uint8_t *prev, size_t prev_step,
                       int channels, int radius, int block, int16_t *flow, size_t flow_step, void *stream);
 
+/* Copy between two device-visible buffers (16-byte aligned; e.g. a module output in HBM -> host memory that is mapped into
+ * the device's address space, hipHostMalloc / a pinned allocation) by a kernel of `workgroups` workgroups (0 = 8).  This is
+ * how a caller that wants disparity / planes in HOST memory -- the reference's consumers read cv::cuda::GpuMat, i.e. device
+ * memory, so this is an extension -- gets them without a full-width copy kernel taking CUs from the compute kernels that
+ * run beside it.  Asynchronous on `stream`. */
+int cart_copy_narrow(cart_engine *engine, void *dst, const void *src, size_t bytes, int workgroups, void *stream);
+
 /* replaces: util::findPeaks (peaks.cpp:12-72). HOST. Arrays hold n entries; returns #peaks, sorted by persistence. */
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right);
 

@@ -174,6 +174,7 @@ static int cmp_u16(const void *a, const void *b) {
 }
 
 void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst) {
+#pragma omp parallel for schedule(static)   /* rows are independent: same values in any order */
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) {
@@ -190,6 +191,7 @@ void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst)
 /* -------------------------------------------------------- S8 + S9 LR/range */
 void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
                                 int w, int h, int min_disp, int16_t *out) {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             size_t i = (size_t)y * w + x;
@@ -301,6 +303,7 @@ void cart_oracle_directional_derivative(const int16_t *disp, int w, int h, int16
 void cart_oracle_plane_derivative(const int16_t *disp, int w, int h, int16_t *out, int32_t *hist256) {
     size_t npx = (size_t)w * h;
     int16_t *lp = (int16_t *)malloc(npx * 2);
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             int16_t sum = 0; /* derivative_t accumulator: wraps like the reference's (:62) */
@@ -415,6 +418,7 @@ int cart_oracle_histogram_peak_params(const int32_t *hist, cart_oracle_plane_par
 /* src/modules/planeseg/planeseg.cu:188-197 */
 void cart_oracle_classify(const int16_t *deriv, int w, int h, const cart_oracle_plane_params *p, uint8_t *planes) {
     size_t npx = (size_t)w * h;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < npx; i++) {
         int d = deriv[i];
         uint8_t plane = 2;
