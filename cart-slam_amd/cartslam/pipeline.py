@@ -102,7 +102,8 @@ class StereoPipeline:
     (PlaneParameterSchedule + cart_find_plane_params), which is what the reference's module does per frame."""
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
-                 with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096, keep_hists=False):
+                 with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096, keep_hists=False,
+                 always_exchange=False):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
@@ -110,6 +111,9 @@ class StereoPipeline:
         self.dev_schedule = DevicePlaneSchedule(engine, provider, static_params, update_interval, reset_interval) if device_schedule else None
         self.with_ccl = with_ccl
         self.keep_hists = keep_hists           # out["hists"]: a copy of this rank's per-frame 256-bin histograms (tests)
+        # always_exchange: run the histogram all-gather and the sequence scatter / gather even in a world of ONE rank, so that
+        # a one-GPU box can push the real collectives (backend nccl = RCCL) through the streams the product path uses
+        self.always_exchange = always_exchange
         self.max_components = max_components   # rows of the per-frame component table (id, label, area, bbox)
         self.group = group
         self.world = 1
@@ -144,7 +148,7 @@ class StereoPipeline:
         share as one batch, gather the named outputs back on `root` in sequence order (None on the other ranks).  With
         world == 1 this is process_batch.  Frame ids continue from the previous call like process_batch's."""
         import torch
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             out = self.process_batch(left, right)
             torch.cuda.current_stream().wait_event(out["done"]) if "done" in out else None
             return {k: out[k] for k in keys}
@@ -173,7 +177,7 @@ class StereoPipeline:
         kept = self._hist.clone() if self.keep_hists else None
         if self.dev_schedule is not None:
             hists = self._hist
-            if self.world > 1 and self.schedule.provider != "static":
+            if (self.world > 1 or self.always_exchange) and self.schedule.provider != "static":
                 on_host = torch.distributed.get_backend(self.group) == "gloo"
                 src = self._hist.cpu() if on_host else self._hist
                 allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=src.device)
@@ -195,7 +199,7 @@ class StereoPipeline:
         if self.schedule.provider == "static":
             per_frame = [self.schedule.params] * n
         else:
-            if self.world > 1:
+            if self.world > 1 or self.always_exchange:
                 # RCCL gathers device tensors; the gloo backend (CPU rehearsals) gathers host copies
                 on_host = torch.distributed.get_backend(self.group) == "gloo"
                 src = self._hist.cpu() if on_host else self._hist

@@ -133,3 +133,30 @@ def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
     assert seen == total
     assert "seq_disp" not in ranks[1].files
     eng.close()
+
+
+def test_rccl_collectives_single_rank(tmp_path):
+    """The collectives of the sharded path on the REAL backend: one RCCL rank (all a one-GPU lease can host) pushes the
+    histogram all-gather -- issued on the pipeline's side stream like in bench.py -- and the sequence scatter / gather
+    through `nccl`, and the results must equal a run without torch.distributed."""
+    import torch
+    from cartslam import Engine
+    from cartslam.pipeline import StereoPipeline
+    from dist_worker import frames_of
+    out = tmp_path / "rccl.npz"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    pr = subprocess.run([sys.executable, os.path.join(HERE, "rccl_single_rank_worker.py"), str(_free_port()), str(out)], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=540)
+    assert pr.returncode == 0, pr.stdout.decode(errors="replace")[-3000:]
+    z = np.load(out)
+    w, h, D, P, n, ui, ri = 256, 96, 64, 8, 6, 4, 2
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n)
+    for dev_sched in (1, 0):
+        pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True, device_schedule=bool(dev_sched))
+        for s in range(3):
+            ls, rs = frames_of(range(s * n + 1, (s + 1) * n + 1), w, h, D, 4321)
+            o = pipe.process_batch(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda())
+            torch.cuda.synchronize()
+            assert (z[f"disp_{dev_sched}_{s}"] == o["disparity"].cpu().numpy()).all(), (dev_sched, s)
+            assert (z[f"planes_{dev_sched}_{s}"] == o["planes"].cpu().numpy()).all(), (dev_sched, s)
+    eng.close()
