@@ -82,6 +82,7 @@ PROTOTYPES = {
     "cart_superpixel_plane_classify": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.POINTER(PlaneParams), _i, C.POINTER(_vp), C.POINTER(_sz),
                                            C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp, _sz, _vp]),
     "cart_optical_flow": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _sz, _vp]),
+    "cart_resize_linear": (_i, [_i, _vp, _sz, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
     "cart_copy_narrow": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "cart_find_plane_params": (_i, [C.POINTER(C.c_int32), C.POINTER(PlaneParams)]),
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),

@@ -470,6 +470,21 @@ class Superpixels:
             pass
 
 
+def resize_linear(img, dst_width, dst_height):
+    """cv::cuda::resize(..., INTER_LINEAR) of the KITTI source (cart_resize_linear): uint8 CUDA [h,w] or [h,w,3] -> [dh,dw(,3)]."""
+    import torch
+    lib = _lib.load()
+    ch = 3 if img.dim() == 3 else 1
+    _, sp, ss, _ = _geom(img, 2 if ch == 3 else 1)
+    sh, sw = img.shape[:2]
+    out = torch.empty((dst_height, dst_width, 3) if ch == 3 else (dst_height, dst_width), dtype=torch.uint8, device=img.device)
+    _, dp, ds, _ = _geom(out, 2 if ch == 3 else 1)
+    rc = lib.cart_resize_linear(img.device.index or 0, sp, ss, sw, sh, ch, dp, ds, dst_width, dst_height, _stream_ptr())
+    if rc != 0:
+        raise EngineError("cart_resize_linear: " + lib.cart_last_error(None).decode())
+    return out
+
+
 def uniq_table(uniqueness_ratio, engine=None):
     """Integer uniqueness thresholds T(best) for best = 0..2047 (cart_debug_uniq_table): from the GPU when an engine is
     given, from the host-compiled copy of the same function otherwise."""

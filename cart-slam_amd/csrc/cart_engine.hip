@@ -1160,6 +1160,18 @@ int cart_optical_flow(cart_engine *e, const uint8_t *cur, size_t cur_step, const
     return 0;
 }
 
+int cart_resize_linear(int device_id, const uint8_t *src, size_t src_step, int sw, int sh, int channels, uint8_t *dst, size_t dst_step, int dw,
+                       int dh, void *stream_) {
+    if (!src || !dst) return fail("NULL image pointer");
+    if (channels != 1 && channels != 3) return fail("channels must be 1 or 3");
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || sw > 16384 || sh > 16384 || dw > 16384 || dh > 16384) return fail("unsupported image size");
+    if (src_step < (size_t)sw * channels || dst_step < (size_t)dw * channels) return fail("step smaller than a row");
+    HIP_TRY(hipSetDevice(device_id));
+    launch_resize_linear(src, src_step, sw, sh, channels, dst, dst_step, dw, dh, static_cast<hipStream_t>(stream_));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int cart_copy_narrow(cart_engine *e, void *dst, const void *src, size_t bytes, int workgroups, void *stream_) {
     if (!e) return fail("engine is NULL");
     if (!dst || !src) return fail("NULL pointer");

@@ -177,6 +177,7 @@ void launch_sp_classify(const SpClassifyArgs &a, hipStream_t s);
 void launch_block_flow(const uint32_t *cen_cur, const uint32_t *cen_prev, const Geometry &g, int radius, int block, int16_t *flow,
                        size_t flow_step, hipStream_t s);
 
+void launch_resize_linear(const uint8_t *src, size_t sstep, int sw, int sh, int channels, uint8_t *dst, size_t dstep, int dw, int dh, hipStream_t s);
 void launch_narrow_copy(const void *src, void *dst, size_t bytes, int blocks, hipStream_t s);
 int kernel_count();
 

@@ -313,6 +313,32 @@ void launch_reproject(const int16_t *disp, size_t step, size_t fs, const QMatrix
     hipLaunchKernelGGL(reproject_kernel, grid, block, 0, s, disp, step, fs, Q, xyz, ostep, ofs, w, h);
 }
 
+// ------------------------------------------------------------------ bilinear resize (KITTI source, oracle S16)
+// kitti.cpp:169-172: cv::cuda::resize(..., INTER_LINEAR) when the configured image size differs from the files'.
+__global__ __launch_bounds__(256) void resize_linear_kernel(const uint8_t *src, size_t sstep, int sw, int sh, int channels, uint8_t *dst, size_t dstep,
+                                                            int dw, int dh, float fx, float fy) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float src_x = (float)x * fx, src_y = (float)y * fy;
+    const int x1 = (int)floorf(src_x), y1 = (int)floorf(src_y), x2 = x1 + 1, y2 = y1 + 1;
+    const int x2r = min(x2, sw - 1), y2r = min(y2, sh - 1);
+    const float wx1 = (float)x2 - src_x, wx2 = src_x - (float)x1, wy1 = (float)y2 - src_y, wy2 = src_y - (float)y1;
+    const uint8_t *r1 = src + (size_t)y1 * sstep, *r2 = src + (size_t)y2r * sstep;
+    for (int c = 0; c < channels; ++c) {
+        float out = 0.f;   // -ffp-contract=off: four multiplies and four adds in this order, like the oracle
+        out = out + (float)r1[x1 * channels + c] * (wx1 * wy1);
+        out = out + (float)r1[x2r * channels + c] * (wx2 * wy1);
+        out = out + (float)r2[x1 * channels + c] * (wx1 * wy2);
+        out = out + (float)r2[x2r * channels + c] * (wx2 * wy2);
+        const float r = rintf(out);
+        dst[(size_t)y * dstep + x * channels + c] = (uint8_t)fminf(fmaxf(r, 0.f), 255.f);
+    }
+}
+void launch_resize_linear(const uint8_t *src, size_t sstep, int sw, int sh, int channels, uint8_t *dst, size_t dstep, int dw, int dh, hipStream_t s) {
+    const float fx = (float)((double)sw / (double)dw), fy = (float)((double)sh / (double)dh);
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(64, 4), 0, s, src, sstep, sw, sh, channels, dst, dstep, dw, dh, fx, fy);
+}
+
 // ------------------------------------------------------------------ plane-parameter schedule (device replay)
 // One block replays the frames of a batch in id order (planeseg.cu:379-403).  At a refresh frame the 256 bins are
 // ranked in parallel (descending value, ties by ascending index: oracle S11), then thread 0 runs the persistence
@@ -777,6 +803,6 @@ void launch_narrow_copy(const void *src, void *dst, size_t bytes, int blocks, hi
     hipLaunchKernelGGL(narrow_copy_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), bytes);
 }
 
-int kernel_count() { return 54; }  // sgm_kernels 26 (census, aggregate x3, pair_sweep x6, wta x6, wta_fused x6, rv_merge, post, uniq_table, +1) + post_kernels 17 + superpixel_kernels 8 + flow 3
+int kernel_count() { return 55; }  // sgm_kernels 26 (census, aggregate x3, pair_sweep x6, wta x6, wta_fused x6, rv_merge, post, uniq_table, +1) + post_kernels 17 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

@@ -60,7 +60,9 @@ namespace sources {
 // calib.txt is required like in the reference unless the frames are PGM/PPM test images.
 class KITTIDataSource : public DataSource {
    public:
-    KITTIDataSource(const std::string &basePath, int sequence);
+    // imageSize (0, 0) = the files' own size; otherwise every frame is resized to it on the device and Q is scaled
+    // (kitti.hpp:11, kitti.cpp:133-148, 169-172)
+    KITTIDataSource(const std::string &basePath, int sequence, Size imageSize = Size{});
     ~KITTIDataSource() override;
     bool isNextReady() override { return !isFinished(); }
     bool isFinished() override;
@@ -75,6 +77,7 @@ class KITTIDataSource : public DataSource {
     std::string dir;
     int currentFrame = 0;
     int readAheadWorkers = 0;
+    Size fileSize{};   // size of the files on disk
     std::unique_ptr<ReadAhead> readAhead;  // started by the first getNext
 };
 }  // namespace sources

@@ -59,7 +59,9 @@ std::shared_ptr<DataSource> createDataSource(const Value &cfg) {
     if (!cfg.is_object()) throw std::runtime_error("Data source configuration is not an object.");
     const std::string sourcePath = cfg.at("path").get<std::string>();
     const std::string type = cfg.at("type").get<std::string>();
-    if (type == "kitti") return std::make_shared<sources::KITTIDataSource>(sourcePath, get(cfg, "sequence", 0));
+    // image_width / image_height are an extension: the reference's factory (cartconfig.cpp:95-98) never passes its ctor's imageSize
+    if (type == "kitti")
+        return std::make_shared<sources::KITTIDataSource>(sourcePath, get(cfg, "sequence", 0), Size{get(cfg, "image_width", 0), get(cfg, "image_height", 0)});
     if (type == "zed") throw std::runtime_error("Data source type zed needs the proprietary ZED SDK: not supported.");
     throw std::runtime_error("Unknown data source type.");
 }

@@ -10,6 +10,8 @@
 #include <thread>
 
 #include "cartslam_amd/png.hpp"
+#include "cart_engine.h"
+#include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <fstream>
@@ -152,37 +154,44 @@ class KITTIDataSource::ReadAhead {
 
 KITTIDataSource::~KITTIDataSource() = default;
 
-KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence) : DataSource(Size{}) {
+KITTIDataSource::KITTIDataSource(const std::string &basePath, int sequence, Size requested) : DataSource(requested) {
     char seq[16];
     std::snprintf(seq, sizeof(seq), "%02d", sequence);
     dir = basePath + "/sequences/" + seq;  // kitti.cpp:89-90
     const std::string calibPath = dir + "/calib.txt";
     std::ifstream calib(calibPath);
     ProjectionRow cams[2];   // P2 = left colour camera, P3 = right
+    bool haveCalib = false;
     if (calib.is_open()) {
         for (std::string line; std::getline(calib, line);) {
             ProjectionRow row;
             if (parseProjectionRow(line, row) && (row.camera == 2 || row.camera == 3)) cams[row.camera - 2] = row;
         }
         if (cams[0].camera != 2 || cams[1].camera != 3) throw std::runtime_error("Failed to read calibration file");  // kitti.cpp:126-128
-        const ProjectionRow &l = cams[0], &r = cams[1];
-        const float base = l.baseline();
-        float *Q = intrinsics.Q;  // kitti.cpp:139-148 (no resize: scale factors are 1)
-        Q[0 * 4 + 3] = -l.cx();
-        Q[1 * 4 + 3] = -l.cy();
-        Q[2 * 4 + 2] = 0;
-        Q[2 * 4 + 3] = l.fx();
-        Q[3 * 4 + 2] = (float)(-1.0 / base);
-        Q[3 * 4 + 3] = (l.cx() - r.cx()) / base;
+        haveCalib = true;
     } else if (std::ifstream(framePath(dir, 2, 0, "png")).is_open()) {
         throw std::runtime_error("Failed to open calibration file at " + calibPath + ": " + std::strerror(errno));  // kitti.cpp:100-103
+    }
+    HostImage first;   // "a bit hacky, but we need to read the first image to get the image size" (kitti.cpp:129-135)
+    if (!readFrame(dir, 2, 0, first)) throw std::runtime_error("Could not read first frame under " + dir);
+    fileSize.width = first.w; fileSize.height = first.h;
+    if (imageSize.width == 0 || imageSize.height == 0) imageSize = fileSize;
+    if (haveCalib) {
+        const float scaleWidth = static_cast<float>(imageSize.width) / fileSize.width;      // kitti.cpp:137-138
+        const float scaleHeight = static_cast<float>(imageSize.height) / fileSize.height;
+        const ProjectionRow &l = cams[0], &r = cams[1];
+        const float base = l.baseline();
+        float *Q = intrinsics.Q;  // kitti.cpp:140-148
+        Q[0 * 4 + 3] = -l.cx() * scaleWidth;
+        Q[1 * 4 + 3] = -l.cy() * scaleHeight;
+        Q[2 * 4 + 2] = 0;
+        Q[2 * 4 + 3] = l.fx() * scaleWidth;
+        Q[3 * 4 + 2] = (float)(-1.0 / base);
+        Q[3 * 4 + 3] = ((l.cx() - r.cx()) * scaleWidth / base);
     }
     // CARTSLAM_READAHEAD = decoder threads (default 4, 0 = read inside getNext like the reference)
     const char *env = std::getenv("CARTSLAM_READAHEAD");
     readAheadWorkers = env ? std::max(0, std::min(16, std::atoi(env))) : 4;
-    HostImage first;
-    if (!readFrame(dir, 2, 0, first)) throw std::runtime_error("Could not read first frame under " + dir);
-    imageSize.width = first.w; imageSize.height = first.h;
 }
 
 bool KITTIDataSource::isFinished() { return !frameExists(dir, 2, currentFrame); }
@@ -204,6 +213,16 @@ std::shared_ptr<DataElement> KITTIDataSource::getNextInternal() {
     image_t dl(l.h, l.w, type), dr(r.h, r.w, type);
     dl.upload(l.data.data(), (size_t)l.w * l.channels);  // kitti.cpp:163-164
     dr.upload(r.data.data(), (size_t)r.w * r.channels);
+    if (imageSize.width != l.w || imageSize.height != l.h) {   // kitti.cpp:169-172: cv::cuda::resize(..., INTER_LINEAR), oracle S16
+        image_t rl(imageSize.height, imageSize.width, type), rr(imageSize.height, imageSize.width, type);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (cart_resize_linear(dev, dl.ptr<uint8_t>(), dl.step, l.w, l.h, l.channels, rl.ptr<uint8_t>(), rl.step, imageSize.width, imageSize.height, nullptr) != 0 ||
+            cart_resize_linear(dev, dr.ptr<uint8_t>(), dr.step, r.w, r.h, r.channels, rr.ptr<uint8_t>(), rr.step, imageSize.width, imageSize.height, nullptr) != 0)
+            throw std::runtime_error(std::string("cart_resize_linear: ") + cart_last_error(nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("resize failed");
+        dl = rl; dr = rr;
+    }
     return std::make_shared<StereoDataElement>(dl, dr);
 }
 }  // namespace cart::sources

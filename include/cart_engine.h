@@ -298,6 +298,12 @@ int cart_superpixel_plane_classify(cart_engine *engine, const int16_t *deriv2, s
 int cart_optical_flow(cart_engine *engine, const uint8_t *cur, size_t cur_step, const uint8_t *prev, size_t prev_step,
                       int channels, int radius, int block, int16_t *flow, size_t flow_step, void *stream);
 
+/* replaces: cv::cuda::resize(src, dst, size, 0, 0, cv::INTER_LINEAR) as KITTIDataSource::getNextInternal applies it when the
+ * configured image size differs from the files' (src/sources/kitti.cpp:169-172); oracle S16.  8-bit, channels = 1 | 3,
+ * device pointers, steps in bytes; needs no engine (no workspace).  device_id selects the GPU. */
+int cart_resize_linear(int device_id, const uint8_t *src, size_t src_step, int src_width, int src_height, int channels,
+                       uint8_t *dst, size_t dst_step, int dst_width, int dst_height, void *stream);
+
 /* Copy between two device-visible buffers (16-byte aligned; e.g. a module output in HBM -> host memory that is mapped into
  * the device's address space, hipHostMalloc / a pinned allocation) by a kernel of `workgroups` workgroups (0 = 8).  This is
  * how a caller that wants disparity / planes in HOST memory -- the reference's consumers read cv::cuda::GpuMat, i.e. device

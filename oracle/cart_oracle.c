@@ -9,6 +9,7 @@
 #include "cart_oracle.h"
 
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -466,6 +467,28 @@ void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float 
 }
 
 /* --------------------------------------------------------------- a-11 CCL */
+/* ------------------------------------------------------------ S16 resize */
+void cart_oracle_resize_linear(const uint8_t *src, int sw, int sh, int channels, uint8_t *dst, int dw, int dh) {
+    const float fx = (float)((double)sw / (double)dw), fy = (float)((double)sh / (double)dh);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const float src_x = (float)x * fx, src_y = (float)y * fy;
+            const int x1 = (int)floorf(src_x), y1 = (int)floorf(src_y), x2 = x1 + 1, y2 = y1 + 1;
+            const int x2r = x2 < sw - 1 ? x2 : sw - 1, y2r = y2 < sh - 1 ? y2 : sh - 1;
+            const float wx1 = (float)x2 - src_x, wx2 = src_x - (float)x1, wy1 = (float)y2 - src_y, wy2 = src_y - (float)y1;
+            for (int c = 0; c < channels; c++) {
+                float out = 0.f;
+                out = out + (float)src[((size_t)y1 * sw + x1) * channels + c] * (wx1 * wy1);
+                out = out + (float)src[((size_t)y1 * sw + x2r) * channels + c] * (wx2 * wy1);
+                out = out + (float)src[((size_t)y2r * sw + x1) * channels + c] * (wx1 * wy2);
+                out = out + (float)src[((size_t)y2r * sw + x2r) * channels + c] * (wx2 * wy2);
+                float r = rintf(out);   /* round half to even (default rounding mode), like __float2int_rn */
+                dst[((size_t)y * dw + x) * channels + c] = (uint8_t)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+            }
+        }
+}
+
 static int uf_find(int32_t *parent, int i) {
     while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
     return i;

@@ -79,6 +79,13 @@
  *                 CPU and GPU agree bit for bit).
  *  S14 YCrCb    = OpenCV 8-bit BGR2YCrCb: Y as S1; Cr = ((R-Y)*11682 + (128<<14) + 8192) >> 14;
  *                 Cb = ((B-Y)*9241 + (128<<14) + 8192) >> 14, arithmetic shift, saturated to u8; stored (Y,Cr,Cb).
+ *  S16 resize     (KITTIDataSource with an image size other than the files', src/sources/kitti.cpp:169-172:
+ *                 cv::cuda::resize(..., INTER_LINEAR) [EXTERNAL-UNVERIFIED: restated from the published
+ *                 opencv cudawarping resize_linear kernel]): no half-pixel offset, src = dst * (src_size /
+ *                 dst_size) in float (the ratio rounded once from double), x1 = floor, x2 = x1 + 1 (read
+ *                 clamped to the last column / row), out = sum over the four taps in the order (y1,x1), (y1,x2),
+ *                 (y2,x1), (y2,x2) of tap * (wx * wy) accumulated in float without contraction, rounded to
+ *                 nearest even and saturated to u8, per channel.
  *  S15 optical flow (stand-in provider of "optflow"; the reference's is NVIDIA fixed-function hardware,
  *                 src/modules/optflow.cpp:57-70, so there is nothing to restate): census block matching, integer pixels.
  *                 For the current pixel p and a displacement (u,v), |u|,|v| <= R:
@@ -180,6 +187,9 @@ void cart_oracle_temporal_vote(const uint8_t *planes, int w, int h, int n_prev, 
 /* SURVEY 8f-2, src/modules/depth.cpp:9-25: disp/16 -> float, cv::cuda::reprojectImageTo3D(Q) (no missing-value
  * handling): [X Y Z W]^T = Q [x y d 1]^T, out = (X/W, Y/W, Z/W) as float [h][w][3].  Float, compare within 1e-4. */
 void cart_oracle_reproject_depth(const int16_t *disp, int w, int h, const float Q[16], float *xyz);
+
+/* S16: tight u8 [sh][sw][channels] -> tight [dh][dw][channels] */
+void cart_oracle_resize_linear(const uint8_t *src, int sw, int sh, int channels, uint8_t *dst, int dw, int dh);
 
 /* a-11 (S12). Returns the number of components. */
 int cart_oracle_ccl(const uint8_t *planes, int w, int h, int32_t *ids);

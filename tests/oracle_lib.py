@@ -203,15 +203,27 @@ def reproject_depth(disp, Q):
     return o
 
 
-def kitti_q_matrix(p2, p3):
-    """Q as KITTIDataSource builds it (src/sources/kitti.cpp:28-86, :139-148) from the 12 numbers of the P2 / P3 rows."""
+def resize_linear(img, dw, dh):
+    """S16: u8 [h,w] or [h,w,3] -> [dh,dw(,3)] (cv::cuda::resize INTER_LINEAR as restated in cart_oracle.h)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    o = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, ch), np.uint8)
+    lib().cart_oracle_resize_linear(_p(img), sw, sh, ch, _p(o), dw, dh)
+    return o
+
+
+def kitti_q_matrix(p2, p3, scale_width=1.0, scale_height=1.0):
+    """Q as KITTIDataSource builds it (src/sources/kitti.cpp:28-86, :137-148) from the 12 numbers of the P2 / P3 rows;
+    scale_* = configured image size / file image size (float32, :137-138)."""
     fx, cx, fubx, cy = np.float32(p2[0]), np.float32(p2[2]), np.float32(p2[3]), np.float32(p2[6])
     cxr = np.float32(p3[2])
+    sw, sh = np.float32(scale_width), np.float32(scale_height)
     baseline = np.float32(-fubx / fx)
     Q = np.eye(4, dtype=np.float32)
-    Q[0, 3] = -cx; Q[1, 3] = -cy; Q[2, 2] = 0; Q[2, 3] = fx
+    Q[0, 3] = -cx * sw; Q[1, 3] = -cy * sh; Q[2, 2] = 0; Q[2, 3] = fx * sw
     Q[3, 2] = np.float32(-1.0 / baseline)
-    Q[3, 3] = np.float32((cx - cxr) / baseline)
+    Q[3, 3] = np.float32((cx - cxr) * sw / baseline)
     return Q
 
 

@@ -853,3 +853,22 @@ def test_integer_uniqueness_threshold_on_device(torch_cuda):
         _check_uniq_table(got, ratio)
         assert (got == uniq_table(ratio)).all(), f"device and host copies differ at ratio {ratio}"
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sw,sh,dw,dh,ch", [(300, 100, 256, 96, 3), (1242, 375, 621, 188, 1), (97, 61, 200, 130, 3), (64, 32, 64, 32, 1), (333, 77, 100, 231, 1)])
+def test_resize_linear(torch_cuda, sw, sh, dw, dh, ch):
+    """cart_resize_linear (KITTI source, kitti.cpp:169-172) against oracle S16: down- and up-scaling, both axes ragged, a
+    pitched source, identity size."""
+    torch = torch_cuda
+    from cartslam.engine import resize_linear
+    rng = np.random.default_rng(sw * 7 + dh)
+    img = rng.integers(0, 256, (sh, sw, 3) if ch == 3 else (sh, sw)).astype(np.uint8)
+    buf = torch.zeros((sh + 2, sw + 13, 3) if ch == 3 else (sh + 2, sw + 13), dtype=torch.uint8, device="cuda")
+    view = buf[:sh, :sw]
+    view.copy_(dev(torch, img))
+    got = resize_linear(view, dw, dh).cpu().numpy()
+    exp = O.resize_linear(img, dw, dh)
+    assert got.shape == exp.shape and (got == exp).all(), f"{int((got != exp).sum())} samples differ, max |diff| {int(np.abs(got.astype(int) - exp.astype(int)).max())}"
+    if (sw, sh) == (dw, dh):
+        assert (got == img).all()

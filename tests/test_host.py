@@ -227,6 +227,26 @@ def test_kitti_png_source_and_depth(tmp_path, color):
 
 
 @pytest.mark.gpu
+def test_kitti_source_resizes_to_the_configured_size(tmp_path):
+    """KITTIDataSource with an image size other than the files' (kitti.hpp:11; kitti.cpp:137-148 scales Q, :169-172 resizes both
+    images with cv::cuda::resize INTER_LINEAR, oracle S16).  The size comes from the `image_width` / `image_height` keys,
+    an extension of the source JSON (the reference's factory never passes its ctor's imageSize)."""
+    tmp = str(tmp_path)
+    w, h, n, dw, dh = 300, 100, 3, 256, 96
+    src, frames = make_kitti_png_dataset(tmp, n, w, h, color=True)
+    cfg = json.load(open(src)); cfg.update(image_width=dw, image_height=dh); json.dump(cfg, open(src, "w"))
+    os.makedirs(os.path.join(tmp, "dump"))
+    r = run_exe(src, [{"type": "disparity", "num_disparities": 64, "smoothing_radius": 2, "smoothing_iterations": 1}], tmp,
+                ("--dump", os.path.join(tmp, "dump")))
+    assert r.returncode == 0, r.stderr
+    Q = np.fromfile(os.path.join(tmp, "dump", "Q.bin"), np.float32).reshape(4, 4)
+    assert np.array_equal(Q, O.kitti_q_matrix(P_ROWS[2], P_ROWS[3], np.float32(dw) / np.float32(w), np.float32(dh) / np.float32(h))), Q
+    for f, (l, rr) in enumerate(frames):
+        ed = O.disparity_module(O.resize_linear(l, dw, dh), O.resize_linear(rr, dw, dh), 64, 4, 4, radius=2, iterations=1)
+        assert (load(tmp, f + 1, "disparity", np.int16, (dh, dw)) == ed).all(), f"disparity of resized frame {f + 1}"
+
+
+@pytest.mark.gpu
 def test_temporal_smoothing_frame_loop(tmp_path):
     """use_temporal_smoothing through the module API: cross-frame dependencies (planes_unsmoothed of runs -1..-3, optflow
     of runs 0..-2; include/modules/planeseg.hpp:127-143) and the tables of planeseg.cu:303-347, flow replayed from files."""

@@ -320,3 +320,17 @@ def test_ccl_component_table_known_answers():
     assert table.tolist() == [[7, 1, 1, 7, 0, 7, 0], [9, 0, 6, 1, 1, 3, 2], [34, 1, 5, 2, 4, 6, 4]]
     t2, n3 = O.ccl_stats(pl, ids, max_components=2)
     assert n3 == 3 and t2.tolist() == table[:2].tolist()
+
+
+def test_resize_linear_known_answers():
+    """S16 by hand: identity at equal size, exact 2x down-sampling picks the even samples (weights 1 / 0), a 2-pixel ramp
+    stretched to 4 gives the quarter-step blend with the last column clamped, and .5 results round to even."""
+    img = np.arange(48, dtype=np.uint8).reshape(6, 8)
+    assert (O.resize_linear(img, 8, 6) == img).all()
+    assert (O.resize_linear(img, 4, 3) == img[::2, ::2]).all()
+    row = np.array([[10, 20]], np.uint8)
+    assert O.resize_linear(row, 4, 1).tolist() == [[10, 15, 20, 20]]          # src_x = 0, .5, 1, 1.5: (10+20)/2 = 15, then x2 clamps
+    assert O.resize_linear(np.array([[1, 2]], np.uint8), 4, 1).tolist() == [[1, 2, 2, 2]]   # 1.5 rounds to even (2)
+    assert O.resize_linear(np.array([[2, 3]], np.uint8), 4, 1).tolist() == [[2, 2, 3, 3]]   # 2.5 rounds to even (2)
+    rgb = np.stack([img, img + 1, img + 2], axis=-1).astype(np.uint8)
+    assert (O.resize_linear(rgb, 4, 3) == rgb[::2, ::2]).all()
