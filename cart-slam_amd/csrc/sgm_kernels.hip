@@ -1200,7 +1200,16 @@ void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_
 // SIMD), so small blocks spread them evenly over the CUs: with 4-wave blocks a quarter of the CUs carried 3 blocks, the
 // rest 2, and the launch took the time of 3.  D=256 keeps 4 waves: its blocks would otherwise be 8 columns wide and the
 // right-view partial rows (columns + D - 1 entries per block and row) would grow to 17 % of the slab traffic.
-constexpr int fused_waves(int lpp) { return lpp >= 16 ? 4 : 2; }
+#ifndef CART_FUSED_WAVES_LE8
+#define CART_FUSED_WAVES_LE8 2
+#endif
+#ifndef CART_FUSED_WAVES_16
+#define CART_FUSED_WAVES_16 4
+#endif
+constexpr int fused_waves(int lpp) { return lpp >= 16 ? CART_FUSED_WAVES_16 : CART_FUSED_WAVES_LE8; }
+// ... except on wide images at D = 256, where blocks of 8 waves (32 columns) give ~one block per CU and halve the partial
+// right-view rows again: 1920x1080, 4 frames: 2.65 instead of 3.08 ms per launch (at 1242 wide 8 waves lose 10 %)
+inline int fused_waves_for(const Geometry &g) { return g.D >= 256 && g.w >= 1600 ? 2 * CART_FUSED_WAVES_16 : fused_waves(g.D / 16); }
 
 
 struct FusedArgs {
@@ -1222,11 +1231,11 @@ struct FusedRegs {
 
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
-template <int LPP, int NP>
-__global__ __launch_bounds__(64 * fused_waves(LPP), 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU)
+template <int LPP, int NP, int WPB_ = fused_waves(LPP)>
+__global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU)
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    constexpr int WPB = fused_waves(LPP), NT = 64 * WPB;
+    constexpr int WPB = WPB_, NT = 64 * WPB;
     constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
     __shared__ uint32_t s_win[WPB][WN::BUF];
     constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
@@ -1501,7 +1510,7 @@ __global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, 
 }
 
 size_t wta_fused_partial_elems(const Geometry &g) {
-    const int cols = fused_waves(g.D / 16) * (64 / (g.D / 16));
+    const int cols = fused_waves_for(g) * (64 / (g.D / 16));
     const int hpad = (g.h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
     return (size_t)hpad * ((g.w + cols - 1) / cols) * (cols + g.D);
 }
@@ -1509,20 +1518,27 @@ size_t wta_fused_partial_elems(const Geometry &g) {
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s) {
     FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq};
-    const int cols = fused_waves(g.D / 16) * (64 / (g.D / 16));
+    const int wpb = fused_waves_for(g), cols = wpb * (64 / (g.D / 16));
     const int nblk = (g.w + cols - 1) / cols;
-    dim3 grid(nblk * n_frames), block(64 * fused_waves(g.D / 16));
+    dim3 grid(nblk * n_frames), block(64 * wpb);
+    const bool wide = wpb != fused_waves(g.D / 16);   // D = 256 on wide images: twice the waves per block
     if (g.P == 4) {
         switch (g.D) {
             case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 4>), grid, block, 0, s, a); break;
             case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 4>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((wta_fused_kernel<16, 4>), grid, block, 0, s, a); break;
+            default:
+                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 4, 2 * CART_FUSED_WAVES_16>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((wta_fused_kernel<16, 4>), grid, block, 0, s, a);
+                break;
         }
     } else {
         switch (g.D) {
             case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 8>), grid, block, 0, s, a); break;
             case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 8>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((wta_fused_kernel<16, 8>), grid, block, 0, s, a); break;
+            default:
+                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 8, 2 * CART_FUSED_WAVES_16>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((wta_fused_kernel<16, 8>), grid, block, 0, s, a);
+                break;
         }
     }
     hipLaunchKernelGGL(rv_merge_kernel, dim3((g.w + 63) / 64, (g.h + 3) / 4, n_frames), dim3(256), 0, s, (const uint32_t *)partial, right_pk,

@@ -545,6 +545,8 @@ FUSED_CASES = [
     (64, 16, 64, 8, 4, 1),        # narrower than D, one block
     (97, 131, 128, 4, 64, 2),
     (257, 33, 128, 8, 4, 9),      # a wave of entirely invalid columns (257 = 8*32 + 1), batch above the default threshold
+    (1700, 12, 256, 8, 4, 2),     # >= 1600 wide at D=256: the sweep's blocks are 8 waves = 32 columns (last block: 4 valid columns)
+    (1605, 9, 256, 4, 11, 1),     # the same with 4 paths
 ]
 
 
