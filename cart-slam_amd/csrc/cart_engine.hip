@@ -387,7 +387,7 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
     std::lock_guard<std::mutex> lk(e->mu);
     out->frames_per_launch = std::min(n_frames, e->chunk_frames);
     out->plan = plan_for(e, out->frames_per_launch);
-    out->slabs_written = out->plan == CART_PLAN_PAIRS ? 5 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
+    out->slabs_written = out->plan == CART_PLAN_PAIRS ? 6 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
     return 0;
 }
 

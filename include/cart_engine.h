@@ -69,9 +69,10 @@ void cart_engine_destroy(cart_engine *engine);
 /* Launch plans of the SGM core.  Every plan produces the same bits; they differ in which path slabs exist in HBM.
  *   SLABS     all P path slabs are written by the aggregation launch and read by the WTA launch (2*P*D bytes / pixel);
  *   FUSED_UP  the "up" path is computed inside the WTA sweep and never stored (2*(P-1)*D bytes / pixel);
- *   PAIRS     (8 paths) {down, down-right} leave ONE u8 slab holding the sum of their penalty parts, {up, up-left} are
- *             computed inside the WTA sweep: 5 slabs instead of 8 (2*5*D bytes / pixel).  Needs 2*p2 <= 255; other
- *             engines fall back to FUSED_UP.
+ *   PAIRS     (8 paths) {down, down-right} and {up, up-right} each ride on one sweep over the image rows and leave ONE u8
+ *             slab holding the sum of their penalty parts: 6 slabs instead of 8 (2*6*D bytes / pixel); the WTA adds the
+ *             shared 4*C back from the census planes.  Needs 2*p2 <= 255; other engines fall back to FUSED_UP.
+ *             Measured slower than SLABS on MI355X: an option, never picked by AUTO.
  * AUTO picks per launch from the measured table in DESIGN.md section 4.  Options are plain integers so that the
  * boundary stays C; nothing in the engine reads the environment. */
 enum { CART_PLAN_AUTO = -1, CART_PLAN_SLABS = 0, CART_PLAN_FUSED_UP = 1, CART_PLAN_PAIRS = 2 };
