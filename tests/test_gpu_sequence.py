@@ -160,3 +160,39 @@ def test_rccl_collectives_single_rank(tmp_path):
             assert (z[f"disp_{dev_sched}_{s}"] == o["disparity"].cpu().numpy()).all(), (dev_sched, s)
             assert (z[f"planes_{dev_sched}_{s}"] == o["planes"].cpu().numpy()).all(), (dev_sched, s)
     eng.close()
+
+
+def test_native_rccl_sharder_single_gpu(tmp_path):
+    """cart_shard_amd (host/src/sharder.cpp: the batched-sequence mode below Python -- ncclCommInitAll, grouped ncclSend /
+    ncclRecv scatter and gather, ncclAllGather of the histograms, device-side schedule replay) with the one GPU a lease has:
+    every collective runs through RCCL with a world of one, and disparity + planes must equal the Python pipeline's."""
+    import torch
+    from cartslam import Engine
+    from cartslam.pipeline import StereoPipeline
+    from dist_worker import frames_of
+    exe = os.path.join(os.path.dirname(HERE), "cart-slam_amd", "build", "cart_shard_amd")
+    assert os.path.exists(exe), "cart_shard_amd not built (make -C cart-slam_amd)"
+    w, h, D, P, n, per_call, ui, ri = 256, 96, 64, 8, 12, 4, 5, 2   # refreshes at ids 1, 6, 11; reset at 11
+    ls, rs = frames_of(range(1, n + 1), w, h, D, 987)
+    ls.tofile(tmp_path / "left.bin"); rs.tofile(tmp_path / "right.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    pr = subprocess.run([exe, str(tmp_path / "left.bin"), str(tmp_path / "right.bin"), str(w), str(h), str(n), str(D), str(P), "1", str(per_call),
+                         str(tmp_path), str(ui), str(ri)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=540)
+    assert pr.returncode == 0, pr.stdout.decode(errors="replace")[-3000:]
+    assert b"pairs_per_s" in pr.stdout
+    disp = np.fromfile(tmp_path / "disparity.bin", np.int16).reshape(n, h, w)
+    planes = np.fromfile(tmp_path / "planes.bin", np.uint8).reshape(n, h, w)
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=per_call)
+    pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=False)
+    for f0 in range(0, n, per_call):
+        o = pipe.process_batch(torch.from_numpy(ls[f0:f0 + per_call]).cuda(), torch.from_numpy(rs[f0:f0 + per_call]).cuda())
+        torch.cuda.synchronize()
+        assert (disp[f0:f0 + per_call] == o["disparity"].cpu().numpy()).all(), f"disparity of frames {f0 + 1}.."
+        assert (planes[f0:f0 + per_call] == o["planes"].cpu().numpy()).all(), f"planes of frames {f0 + 1}.."
+    assert len(np.unique(planes)) == 3
+    eng.close()
+    # a box with one GPU must refuse two
+    pr = subprocess.run([exe, str(tmp_path / "left.bin"), str(tmp_path / "right.bin"), str(w), str(h), str(n), str(D), str(P), "2", "4", str(tmp_path)],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    if torch.cuda.device_count() < 2:
+        assert pr.returncode != 0 and b"GPUs" in pr.stdout
