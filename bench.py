@@ -133,7 +133,7 @@ def launch_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1242)
@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
+    ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (default: on for 8 paths, off for 4, where it measures slower)")
     ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -183,13 +184,14 @@ def main():
 
     w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
-                 max_inflight=B if args.no_overlap else 2 * B, device_id=dev_index)
+                 max_inflight=2 * B, device_id=dev_index)
     if args.plan != "auto":
         eng.set_plan(args.plan)
     if args.chunk:
         eng.set_chunk_frames(args.chunk)
     plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
-    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=not args.no_overlap)
+    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True,
+                          overlap=False if args.no_overlap else True if args.overlap else "auto")
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     n_distinct = min(B, 4)
     ls, rs = synth.make_batch(n_distinct, w, h, D, 4, first_frame=rank * n_distinct)
@@ -346,7 +348,7 @@ def main():
                                     (1242, 375, 64, 4): "BASELINE.json configs[1]",
                                     (1920, 1080, 256, 8): "BASELINE.json configs[3]"}.get((w, h, D, P), "not a BASELINE.json configuration"),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}",
-                       "launch_plan": plan,
+                       "launch_plan": plan, "two_stream_pipelining": pipe.side is not None,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": roof_kernel,

@@ -128,6 +128,11 @@ class StereoPipeline:
         # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
         # order.  Outputs other than "disparity" are then produced on `self.side`: synchronise (or wait for
         # out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
+        # overlap="auto": only for 8-path engines.  Measured (profiles/tools/stream_priority.py, 16 pairs per step): 8 paths
+        # gain 2-8 % (D=128: 2.89 vs 3.15 ms), 4 paths LOSE 2-8 % (D=64: 1.23 vs 1.19 ms, D=128: 2.00 vs 1.85) -- their
+        # aggregation launch is bound by the W-step chain of the horizontal scans, which the side stream's kernels slow down.
+        if overlap == "auto":
+            overlap = engine.P == 8
         self.side = torch.cuda.Stream() if overlap else None
 
     def process_batch(self, left, right):
