@@ -347,23 +347,33 @@ void launch_resize_linear(const uint8_t *src, size_t sstep, int sw, int sh, int 
 __global__ __launch_bounds__(256) void plane_schedule_kernel(ScheduleState *state, int provider, int first_id, int n_frames,
                                                              int update_interval, int reset_interval, const int32_t *hists,
                                                              cart_plane_params *params_out) {
-    __shared__ int32_t cum[256], hsnap[256];
+    __shared__ int32_t hsnap[256];
     __shared__ int order[256], owner[256];
     __shared__ int born[130], died[130], lft[130], rgt[130];
     __shared__ cart_plane_params cur;
     const int t = threadIdx.x;
-    cum[t] = state->cum[t];
+    int32_t cumr = state->cum[t];   // this thread's bin of the cumulative histogram
     if (t == 0) cur = state->params;
     __syncthreads();
+    // the frames' histogram bins of this thread, fetched 16 frames at a time BEFORE the serial replay: one load per frame
+    // inside the loop put a global-memory round trip (~2 us) on every frame's critical path, 30 us per 16-frame launch
+    int32_t hv[16];
     for (int k = 0; k < n_frames; ++k) {
         const int fid = first_id + k;
-        cum[t] += hists[(size_t)k * 256 + t];
-        const bool refresh = fid % update_interval == 1;                          // planeseg.cu:381
-        if (refresh) {
-            hsnap[t] = cum[t];                                                    // "download" (:389)
-            if (fid % (update_interval * reset_interval) == 1) cum[t] = 0;        // reset after download (:391-394)
+        if ((k & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hv[j] = k + j < n_frames ? hists[(size_t)(k + j) * 256 + t] : 0;
         }
-        __syncthreads();
+        int32_t add = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) add = (k & 15) == j ? hv[j] : add;   // register select: no dynamic indexing (scratch)
+        cumr += add;
+        const bool refresh = fid % update_interval == 1;                          // planeseg.cu:381
+        if (refresh) {   // block-uniform; frames in between touch nothing shared and need no barrier
+            hsnap[t] = cumr;                                                      // "download" (:389)
+            if (fid % (update_interval * reset_interval) == 1) cumr = 0;          // reset after download (:391-394)
+            __syncthreads();
+        }
         if (refresh && provider == 1) {
             const int v = hsnap[t];
             int rank = 0;
@@ -414,10 +424,9 @@ __global__ __launch_bounds__(256) void plane_schedule_kernel(ScheduleState *stat
             }
             __syncthreads();
         }
-        if (t == 0) params_out[k] = cur;
-        __syncthreads();
+        if (t == 0) params_out[k] = cur;   // `cur` is written and read by thread 0 only
     }
-    state->cum[t] = cum[t];
+    state->cum[t] = cumr;
     if (t == 0) state->params = cur;
 }
 
