@@ -480,10 +480,10 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     if (fr.out_step < (size_t)g.w * 2 || (fr.out_step & 1)) return fail("out_step must be even and >= 2*width");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(e->params.device_id));
-    int chunk_frames, opt_plan, opt_min;
+    int chunk_frames;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        chunk_frames = e->chunk_frames; opt_plan = e->opt_plan; opt_min = e->opt_plan_min_frames;
+        chunk_frames = e->chunk_frames;
         const int launch_plan = plan_for(e, std::min(n_frames, chunk_frames));
         if (launch_plan == CART_PLAN_FUSED_UP && !e->rv_partial)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
@@ -499,7 +499,6 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
             HIP_TRY(hipMemset(e->pair_xch, 0, words * sizeof(unsigned long long)));
         }
     }
-    (void)opt_plan; (void)opt_min;
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
