@@ -981,6 +981,17 @@ void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *sl
 //   * the summed costs of the tile live in LDS as u16 [64][D]: sub-pixel neighbours and the right-view
 //     diagonal minima S(p+d, d) (oracle S6) come from there; per-tile right minima are merged across tiles
 //     with one packed atomicMin per right pixel and tile.
+// The fused sweep's right-view rows (one u32 key per right pixel of a block row) can be indexed through rv_slot: one pad per
+// 16 entries.  The lanes that own one pixel hold disparity chunks 16 apart, so their candidates for one `da` land 16 entries
+// apart -- on TWO of the 32 LDS banks without the pad (8-way conflicts on every ds_min_u32 at D = 256), on 16 different
+// banks with it.  Used where it measured faster: D = 256 / 4 paths (sweep 1.58 -> 1.43 ms per 16 pairs).  The 8-path sweeps
+// sit at the 168-VGPR limit of three waves per SIMD and the 16 slot addresses spill (D = 256 / 8 paths: 2.5 -> 4.0 ms), and
+// the two-kernel WTA did not move (2.03 ms at D = 256 with or without).
+__host__ __device__ constexpr int rv_slot(int i) { return i + (i >> 4); }
+__host__ __device__ constexpr int rv_size(int n) { return ((n + (n >> 4) + 1) + 3) & ~3; }   // slots for n entries (+ a spare), multiple of 4
+// slot of entry base - j for j in [0, 15], from s0 = rv_slot(base) and b4 = base & 15 (base >= 15)
+__device__ __forceinline__ int rv_slot_below(int s0, int b4, int j) { return s0 - j - (j > b4 ? 1 : 0); }
+
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
@@ -1236,7 +1247,8 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = WPB_, NT = 64 * WPB;
-    constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = NR + 1;
+    constexpr bool RVPAD = LPP == 16 && NP == 4;   // see rv_slot
+    constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = RVPAD ? rv_size(NR) : NR + 1;   // slots per row, the last one a spare
     __shared__ uint32_t s_win[WPB][WN::BUF];
     constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * DP];
@@ -1371,12 +1383,15 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
         const uint32_t tot = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d
         if (valid && !(CART_FUSED_ABLATE & (2 | 64))) {
-            uint32_t *rm = &s_rmin[lr][xl + D - 1 - d0];
+            uint32_t *rrow = &s_rmin[lr][0];
+            const int base = xl + D - 1 - d0, s0 = RVPAD ? rv_slot(base) : base;
+            int b4 = base & 15;
+            if constexpr (RVPAD) asm volatile("" : "+v"(b4));   // recompute the 16 slots every row: hoisted, they spill
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
-                atomicMin(rm - da, (sm[q] << 16) | (uint32_t)(d0 + da));
-                atomicMin(rm - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+                atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da) : s0 - da), (sm[q] << 16) | (uint32_t)(d0 + da));
+                atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da + 1) : s0 - da - 1), (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
             }
         }
         // No block barrier: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave (LDS
@@ -1439,7 +1454,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
             }
             const bool live = r < nrows && x0 + c < g.w && i0 + (int)threadIdx.x < RB * COLS;
             uint16_t *dst = live ? a.wta_l + (size_t)frame * g.npx + (size_t)(g.h - 1 - t0 - r) * g.w + x0 + c
-                                 : reinterpret_cast<uint16_t *>(pbase + NR);   // the pad entry of the chunk's first row
+                                 : reinterpret_cast<uint16_t *>(pbase + NRP - 1);   // the spare slot of the chunk's first row
             if (!(CART_FUSED_ABLATE & 16)) *dst = (uint16_t)out;
         }
         static_assert(RB * NRP % 4 == 0, "the right-view rows are copied 16 bytes per lane");
@@ -1498,21 +1513,25 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
 // right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p.
 // partial = [frame][block][sweep step t = h-1-y][cols + D] (rows padded, see wta_fused_kernel's flush)
 constexpr int kFusedRB = 16;
-__global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk) {
+__global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk, int padded) {
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
     if (p >= w || y >= h) return;
-    const int nrp = cols + D, hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
+    const int nrp = padded ? rv_size(cols + D - 1) : cols + D, hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
     const int b0 = p / cols, b1 = min((p + D - 1) / cols, nblk - 1);
     uint32_t best = 0xffffffffu;
-    for (int b = b0; b <= b1; ++b)
-        best = min(best, partial[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (p - (b * cols - (D - 1)))]);
+    for (int b = b0; b <= b1; ++b) {
+        const int e = p - (b * cols - (D - 1));
+        best = min(best, partial[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (padded ? rv_slot(e) : e)]);
+    }
     right_pk[((size_t)frame * h + y) * w + p] = best;
 }
+
+inline bool fused_rv_padded(const Geometry &g) { return g.D >= 256 && g.P == 4; }   // = RVPAD of the kernel that will run
 
 size_t wta_fused_partial_elems(const Geometry &g) {
     const int cols = fused_waves_for(g) * (64 / (g.D / 16));
     const int hpad = (g.h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
-    return (size_t)hpad * ((g.w + cols - 1) / cols) * (cols + g.D);
+    return (size_t)hpad * ((g.w + cols - 1) / cols) * (fused_rv_padded(g) ? rv_size(cols + g.D - 1) : cols + g.D);
 }
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
@@ -1542,7 +1561,7 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_
         }
     }
     hipLaunchKernelGGL(rv_merge_kernel, dim3((g.w + 63) / 64, (g.h + 3) / 4, n_frames), dim3(256), 0, s, (const uint32_t *)partial, right_pk,
-                       g.w, g.h, g.D, cols, nblk);
+                       g.w, g.h, g.D, cols, nblk, fused_rv_padded(g) ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ median x2 + LR check + range fix
