@@ -11,6 +11,8 @@ from cartslam.pipeline import StereoPipeline
 w, h, D, P, B = 1242, 375, 128, 8, 16
 steps = int(os.environ.get("STEPS", 400))
 eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * B)
+if os.environ.get("PLAN"):   # PLAN=pairs | fused_up | slabs: soak one launch plan (all must reproduce the first step bit for bit)
+    eng.set_plan(os.environ["PLAN"])
 pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=True)
 ls, rs = synth.make_batch(4, w, h, D, 4)
 L = torch.from_numpy(np.concatenate([ls] * 4)).cuda(); R = torch.from_numpy(np.concatenate([rs] * 4)).cuda()
@@ -41,5 +43,7 @@ for s in range(steps):
     if not ok:
         bad += 1; print("step", s, "CCL invariant violated")
 torch.cuda.synchronize()
-print(f"soak: {steps} steps x {B} pairs in {time.time() - t0:.1f} s, {bad} bad steps")
+status = eng.device_status()
+print(f"soak: {steps} steps x {B} pairs in {time.time() - t0:.1f} s, {bad} bad steps, plan {eng.describe_plan(B)['plan']}, device status {status}")
+bad += status != 0
 sys.exit(1 if bad else 0)
