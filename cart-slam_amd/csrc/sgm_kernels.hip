@@ -1068,6 +1068,18 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     }
 
     uint32_t pk_res[NPASS], tot_res[NPASS];
+    constexpr bool PREFETCH = NPASS >= 4;
+    v4u pf[PREFETCH ? 2 : 1][PREFETCH ? kMaxPaths : 1];
+    auto issue_pass = [&](int pass, v4u (&dst)[PREFETCH ? kMaxPaths : 1]) {
+        if constexpr (PREFETCH) {
+            const int xcp = min(x0 + pass * PPP + grp, g.w - 1);
+            const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xcp) * D + d0;
+#pragma unroll
+            for (int r = 0; r < kMaxPaths; ++r)
+                if (r < a.nslabs) dst[r] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)a.slab_idx[r] * g.slab_bytes));
+        }
+    };
+    if constexpr (PREFETCH) issue_pass(0, pf[0]);
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int xl = pass * PPP + grp;
@@ -1078,13 +1090,30 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         uint32_t sm[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) sm[k] = 0;
-        const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xc) * D + d0;
-        for (int r = 0; r < a.nslabs; ++r) {
-            const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)a.slab_idx[r] * g.slab_bytes));
+        if constexpr (PREFETCH) {
+            // D = 256: four passes per block and four blocks per CU (LDS) -- with every pass waiting for its own loads the
+            // launch ran at memory latency (7.6 GB in 2.0 ms); the next pass's slab bytes are requested before this pass computes
+            if (pass + 1 < NPASS) issue_pass(pass + 1, pf[(pass + 1) & 1]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                sm[q] += v[q] & 0x00ff00ffu;
-                sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
+            for (int r = 0; r < kMaxPaths; ++r) {
+                if (r < a.nslabs) {
+                    const v4u v = pf[pass & 1][r];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sm[q] += v[q] & 0x00ff00ffu;
+                        sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
+                    }
+                }
+            }
+        } else {
+            const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xc) * D + d0;
+            for (int r = 0; r < a.nslabs; ++r) {
+                const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)a.slab_idx[r] * g.slab_bytes));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sm[q] += v[q] & 0x00ff00ffu;
+                    sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
+                }
             }
         }
         if constexpr (PAIRS) {
