@@ -1247,6 +1247,10 @@ void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_
 #define CART_FUSED_WAVES_16 4
 #endif
 constexpr int fused_waves(int lpp) { return lpp >= 16 ? CART_FUSED_WAVES_16 : CART_FUSED_WAVES_LE8; }
+#ifndef CART_FUSED_RB
+#define CART_FUSED_RB 16
+#endif
+constexpr int kFusedRB = CART_FUSED_RB;   // rows buffered in LDS between two bursts of the fused sweep
 // ... except on wide images at D = 256, where blocks of 8 waves (32 columns) give ~one block per CU and halve the partial
 // right-view rows again: 1920x1080, 4 frames: 2.65 instead of 3.08 ms per launch (at 1242 wide 8 waves lose 10 %)
 inline int fused_waves_for(const Geometry &g) { return g.D >= 256 && g.w >= 1600 ? 2 * CART_FUSED_WAVES_16 : fused_waves(g.D / 16); }
@@ -1272,7 +1276,7 @@ struct FusedRegs {
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
 template <int LPP, int NP, int WPB_ = fused_waves(LPP)>
-__global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU)
+__global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU); 4 for the 4-path variants (120 VGPRs, 39 KB of LDS) measured the same
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = WPB_, NT = 64 * WPB;
@@ -1281,10 +1285,11 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     __shared__ uint32_t s_win[WPB][WN::BUF];
     constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * DP];
-    constexpr int RB = 16;                       // rows buffered in LDS between two bursts (= kFusedRB; 32 rows cost an LDS-limited block per CU)
+    constexpr int RB = kFusedRB;                 // rows buffered in LDS between two bursts (32 rows cost an LDS-limited block per CU)
     __shared__ __attribute__((aligned(16))) uint32_t s_rmin[RB][NRP];
     __shared__ uint2 s_rec[RB][COLS];            // per pixel: best disparity, unique flag, best cost | its two neighbour costs
-    __shared__ uint16_t s_thr[2048];             // uniqueness threshold by best cost (sums are <= 8 * 255)
+    constexpr int NTHR = NP <= 4 ? 1024 : 2048;  // sums are <= NP * 255
+    __shared__ uint16_t s_thr[NTHR];             // uniqueness threshold by best cost
     const Geometry &g = a.g;
     const int nblk = (g.w + COLS - 1) / COLS;
     const int frame = blockIdx.x / nblk, blk = blockIdx.x - frame * nblk, x0 = blk * COLS;
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
 
     for (int i = threadIdx.x; i < RB * NRP; i += NT) (&s_rmin[0][0])[i] = 0xffffffffu;
-    for (int i = threadIdx.x; i < 2048; i += NT) s_thr[i] = (uint16_t)uniq_threshold((uint32_t)i, a.uniq);
+    for (int i = threadIdx.x; i < NTHR; i += NT) s_thr[i] = (uint16_t)uniq_threshold((uint32_t)i, a.uniq);
 
     // right-census window of the wave (see aggregate_kernel): cooperative load offsets + this lane's read slots
     WinLane<LPP> wlane;
@@ -1464,7 +1469,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     // acknowledgement of the burst's own stores: ~13 us per burst, 0.3 ms per 16-frame launch.
     auto flush = [&](int t0, int nrows) {   // LDS row r = sweep step t0 + r = image row h-1-t0-r
         if (CART_FUSED_ABLATE & 512) return;   // timing experiment: no burst
-        lds_barrier();
+        if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();   // 2048: burst without its two barriers
         uint32_t *pbase = a.partial + (((size_t)frame * nblk + blk) * (size_t)hpad + t0) * NRP;
 #pragma unroll
         for (int i0 = 0; i0 < RB * COLS; i0 += NT) {
@@ -1502,7 +1507,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
                             : reinterpret_cast<v4u *>(a.partial + (((size_t)frame * nblk + blk + 1) * (size_t)hpad) * NRP) - 1;
             if (!(CART_FUSED_ABLATE & 8)) *dst = v;
         }
-        lds_barrier();
+        if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();
     };
 
     __syncthreads();
@@ -1541,7 +1546,6 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
 
 // right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p.
 // partial = [frame][block][sweep step t = h-1-y][cols + D] (rows padded, see wta_fused_kernel's flush)
-constexpr int kFusedRB = 16;
 __global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk, int padded) {
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
     if (p >= w || y >= h) return;
