@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -198,13 +199,21 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
 }
 
+// The options a call works with: read once under the engine's mutex, so that a concurrent cart_engine_set_option
+// cannot change the plan between the workspace allocation and the launches of one call.
+struct Options {
+    int plan, plan_min_frames, chunk_frames;
+    bool timing;
+};
+Options snapshot_options(const cart_engine *e) { return Options{e->opt_plan, e->opt_plan_min_frames, e->chunk_frames, e->timing}; }   // caller holds e->mu
+
 // The launch plan of `n` frames handed to one launch sequence (include/cart_engine.h, CART_PLAN_*).
-int plan_for(const cart_engine *e, int n) {
-    if (e->opt_plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
-    if (n < e->opt_plan_min_frames) return CART_PLAN_SLABS;
+int plan_for(const cart_engine *e, const Options &o, int n) {
+    if (o.plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
+    if (n < o.plan_min_frames) return CART_PLAN_SLABS;
     // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP
-    if (e->opt_plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255)) return CART_PLAN_FUSED_UP;
-    return e->opt_plan;
+    if (o.plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255)) return CART_PLAN_FUSED_UP;
+    return o.plan;
 }
 
 int validate(const cart_engine_params *p) {
@@ -385,8 +394,9 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (n_frames < 1) return fail("n_frames must be positive");
     std::lock_guard<std::mutex> lk(e->mu);
-    out->frames_per_launch = std::min(n_frames, e->chunk_frames);
-    out->plan = plan_for(e, out->frames_per_launch);
+    const Options o = snapshot_options(e);
+    out->frames_per_launch = std::min(n_frames, o.chunk_frames);
+    out->plan = plan_for(e, o, out->frames_per_launch);
     out->slabs_written = out->plan == CART_PLAN_PAIRS ? 6 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
     return 0;
 }
@@ -480,30 +490,31 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     if (fr.out_step < (size_t)g.w * 2 || (fr.out_step & 1)) return fail("out_step must be even and >= 2*width");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(e->params.device_id));
-    int chunk_frames;
+    Options opt;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        chunk_frames = e->chunk_frames;
-        const int launch_plan = plan_for(e, std::min(n_frames, chunk_frames));
+        opt = snapshot_options(e);
+        const int launch_plan = plan_for(e, opt, std::min(n_frames, opt.chunk_frames));   // later (shorter) launches of the call never need more
         if (launch_plan == CART_PLAN_FUSED_UP && !e->rv_partial)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
         if (launch_plan == CART_PLAN_PAIRS && !e->pair_xch) {
             // zeroed once: epoch 0 never tags a launch, so a word that was never written cannot pass for a hand-over
             const size_t words = 2 * e->slots.size() * pair_xch_elems(g);   // one area per sweep direction: they run concurrently
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_ticket), 2 * e->slots.size() * sizeof(uint32_t)));
+            if (!e->pair_ticket) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_ticket), 2 * e->slots.size() * sizeof(uint32_t)));
             HIP_TRY(hipMemset(e->pair_ticket, 0, 2 * e->slots.size() * sizeof(uint32_t)));
-
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dev_status), sizeof(uint32_t)));
+            if (!e->dev_status) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dev_status), sizeof(uint32_t)));
             HIP_TRY(hipMemset(e->dev_status, 0, sizeof(uint32_t)));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_xch), words * sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(e->pair_xch, 0, words * sizeof(unsigned long long)));
+            unsigned long long *xch = nullptr;   // published last: the launches below take e->pair_xch as "everything is there"
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&xch), words * sizeof(unsigned long long)));
+            if (hipMemset(xch, 0, words * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(xch); return fail("hipMemset of the hand-over area failed"); }
+            e->pair_xch = xch;
         }
     }
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
     TimingRec *rec = nullptr;
-    if (e->timing) {
+    if (opt.timing) {
         std::lock_guard<std::mutex> lk(e->mu);
         if (!e->ring.empty()) { rec = &e->ring[e->ring_calls++ % kTimingRing]; rec->n = 0; }
     }
@@ -526,7 +537,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         if (!timed) rec = nullptr;
         STAGE("census");
         launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
-        const int launch_plan = plan_for(e, n);
+        const int launch_plan = plan_for(e, opt, n);
         const bool pairs = launch_plan == CART_PLAN_PAIRS && e->pair_xch;
         const bool fused = launch_plan == CART_PLAN_FUSED_UP && e->rv_partial;
         STAGE(pairs ? "pair_down" : "aggregate");
@@ -580,7 +591,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     // Large batches run as cache-sized sub-batches on the caller's stream: the census planes every direction
     // re-reads (4.2 MB per frame) then stay in L2 + Infinity Cache (measured: 64 frames in one launch are 13 %
     // slower per frame than 4 x 16).  Two-stream overlap of sub-batches was measured and buys nothing.
-    const int chunk = fr.lefts ? std::min(chunk_frames, kLaunchFrames) : chunk_frames;  // pointer tables hold kLaunchFrames entries
+    const int chunk = fr.lefts ? std::min(opt.chunk_frames, kLaunchFrames) : opt.chunk_frames;  // pointer tables hold kLaunchFrames entries
     for (int f0 = 0; f0 < n_frames; f0 += chunk) enqueue(f0, std::min(chunk, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
     release(l);
@@ -800,7 +811,7 @@ int cart_plane_ccl_stats(cart_engine *e, int n_frames, const uint8_t *planes, si
 }
 
 struct cart_plane_schedule {
-    cart_engine *engine;
+    int device_id;         // the engine's; kept here so that the schedule can outlive the engine it was created on
     ScheduleState *state;  // device
     int provider, update_interval, reset_interval;
 };
@@ -811,7 +822,7 @@ int cart_plane_schedule_create(cart_engine *e, int provider, const cart_plane_pa
     if (provider != 0 && provider != 1) return fail("Unknown parameter provider type.");
     if (update_interval < 1 || reset_interval < 1) return fail("intervals must be >= 1");
     HIP_TRY(hipSetDevice(e->params.device_id));
-    cart_plane_schedule *s = new (std::nothrow) cart_plane_schedule{e, nullptr, provider, update_interval, reset_interval};
+    cart_plane_schedule *s = new (std::nothrow) cart_plane_schedule{e->params.device_id, nullptr, provider, update_interval, reset_interval};
     if (!s) return fail("out of host memory");
     ScheduleState init;
     std::memset(&init, 0, sizeof(init));
@@ -827,6 +838,7 @@ int cart_plane_schedule_create(cart_engine *e, int provider, const cart_plane_pa
 
 void cart_plane_schedule_destroy(cart_plane_schedule *s) {
     if (!s) return;
+    (void)hipSetDevice(s->device_id);   // the caller's current device may be another one
     if (s->state) (void)hipFree(s->state);
     delete s;
 }
@@ -835,7 +847,7 @@ int cart_plane_schedule_advance(cart_plane_schedule *s, int first_id, int n_fram
                                 cart_plane_params *params_out, void *stream) {
     if (!s || !hists || !params_out) return fail("bad arguments");
     if (n_frames <= 0 || first_id < 1) return fail("n_frames must be positive and ids are 1-based");
-    HIP_TRY(hipSetDevice(s->engine->params.device_id));
+    HIP_TRY(hipSetDevice(s->device_id));
     launch_plane_schedule(s->state, s->provider, first_id, n_frames, s->update_interval, s->reset_interval, hists, params_out,
                           static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
@@ -844,7 +856,7 @@ int cart_plane_schedule_advance(cart_plane_schedule *s, int first_id, int n_fram
 
 int cart_plane_schedule_read(cart_plane_schedule *s, cart_plane_params *params_host, int32_t cum_hist_host[256]) {
     if (!s) return fail("bad arguments");
-    HIP_TRY(hipSetDevice(s->engine->params.device_id));
+    HIP_TRY(hipSetDevice(s->device_id));
     HIP_TRY(hipDeviceSynchronize());
     ScheduleState st;
     HIP_TRY(hipMemcpy(&st, s->state, sizeof(st), hipMemcpyDeviceToHost));
@@ -1186,6 +1198,7 @@ int cart_copy_narrow(cart_engine *e, void *dst, const void *src, size_t bytes, i
 // ---- host-side peak finder (replaces src/utils/peaks.cpp:12-72 and planeseg.cu:405-458) ----
 int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left, int *right) {
     if (!data || n <= 0 || !born || !died || !left || !right) return fail("bad arguments");
+    try {
     std::vector<int> order(n), owner(n, -1);
     for (int i = 0; i < n; ++i) order[i] = i;
     // descending value, ties by ascending index (oracle S11; the reference's std::sort leaves ties open)
@@ -1217,6 +1230,7 @@ int cart_find_peaks(const int32_t *data, int n, int *born, int *died, int *left,
     for (int i = 0; i < np; ++i) { b2[i] = born[perm[i]]; d2[i] = died[perm[i]]; l2[i] = left[perm[i]]; r2[i] = right[perm[i]]; }
     for (int i = 0; i < np; ++i) { born[i] = b2[i]; died[i] = d2[i]; left[i] = l2[i]; right[i] = r2[i]; }
     return np;
+    } catch (const std::bad_alloc &) { return fail("out of host memory"); }   // nothing is thrown across the C ABI
 }
 
 int cart_find_plane_params(const int32_t hist[256], cart_plane_params *io) {
@@ -1266,6 +1280,7 @@ int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, si
     HIP_TRY(hipDeviceSynchronize());
     const void *src = nullptr;
     size_t need = 0;
+    try {
     if (what == CART_DBG_GRAY_L || what == CART_DBG_GRAY_R) {
         src = (what == CART_DBG_GRAY_L ? e->gray_l : e->gray_r) + (size_t)slot * g.npx; need = g.npx;
         if (bytes < need) return fail("buffer too small");
@@ -1297,6 +1312,7 @@ int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, si
     } else {
         return fail("unknown debug selector");
     }
+    } catch (const std::bad_alloc &) { return fail("out of host memory"); }   // the staging vectors (a slab is up to 530 MB)
     return 0;
 }
 
