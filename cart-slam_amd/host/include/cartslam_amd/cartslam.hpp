@@ -7,13 +7,17 @@
 
 #define CARTSLAM_RUN_RETENTION 32
 #define CARTSLAM_CONCURRENT_RUN_LIMIT 12
+#define CARTSLAM_WORKER_THREADS (16 * CARTSLAM_CONCURRENT_RUN_LIMIT)
 
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "data.hpp"
@@ -29,6 +33,39 @@ size_t concurrentRunLimit();
 
 class System;
 
+// The worker pool every frame task, module waiter and SyncWrapperSystemModule::run is posted to (the reference's
+// boost::asio::thread_pool, include/cartslam.hpp:5,104: 16 x run-limit threads).  Threads are started on demand and kept;
+// a task that finds no idle worker gets a new one even beyond `workerThreads`, so that tasks blocked on their
+// dependencies can never starve the task that provides them (a fixed pool deadlocks on a long module list with many
+// frames in flight; the reference's 192 threads merely make that unlikely).
+class WorkerPool {
+   public:
+    explicit WorkerPool(size_t workerThreads) : workerThreads(workerThreads) {}
+    ~WorkerPool();   // runs what is queued, then joins
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+
+    template <class F>
+    auto post(F &&f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::forward<F>(f));
+        auto future = task->get_future();
+        enqueue([task]() { (*task)(); });
+        return future;
+    }
+    size_t threadCount();      // threads started so far (diagnostics)
+    const size_t workerThreads;   // nominal size
+
+   private:
+    void enqueue(std::function<void()> fn);
+    void work();
+    std::mutex mutex;
+    std::condition_variable wake;
+    std::deque<std::function<void()>> queue;
+    std::vector<std::thread> threads;
+    size_t idle = 0;
+    bool stopping = false;
+};
+
 class SystemRunData : public DataContainer {
    public:
     SystemRunData(uint32_t id, System *system, std::shared_ptr<DataElement> dataElement) : dataElement(dataElement), id(id), system(system) {}
@@ -43,7 +80,7 @@ class SystemRunData : public DataContainer {
 class System : public DataContainer {
    public:
     explicit System(std::shared_ptr<DataSource> dataSource, size_t runRetention = CARTSLAM_RUN_RETENTION,
-                    size_t concurrentRunLimit = cart::concurrentRunLimit());
+                    size_t concurrentRunLimit = cart::concurrentRunLimit(), size_t workerThreads = 0 /* 16 x concurrentRunLimit */);
     ~System();
 
     // one frame: next data element, every module once (cartslam.cpp:228-334). The future resolves when all
@@ -64,6 +101,7 @@ class System : public DataContainer {
     std::shared_ptr<SystemRunData> getRunById(const uint32_t id);
     void insertGlobalData(const std::string &key, std::shared_ptr<void> data) { insertData(std::make_pair(key, data)); }
     const std::shared_ptr<DataSource> getDataSource() const { return dataSource; }
+    WorkerPool &getThreadPool() { return threadPool; }   // include/cartslam.hpp:86
     const std::vector<std::shared_ptr<SystemModule>> &getModules() const { return modules; }
 
    private:
@@ -78,5 +116,6 @@ class System : public DataContainer {
     std::vector<std::shared_ptr<SystemRunData>> runs;
     std::mutex runMutex;
     std::condition_variable runCondition;
+    WorkerPool threadPool;   // last member: destroyed (drained and joined) first, while everything its tasks touch is still alive
 };
 }  // namespace cart

@@ -8,9 +8,52 @@
 
 namespace cart {
 
-// src/modules/module.cpp:7-19: post runInternal to a worker and hand back its future
+// src/modules/module.cpp:7-19: post runInternal to the system's worker pool and hand back its future
 std::future<system_data_t> SyncWrapperSystemModule::run(System &system, SystemRunData &data) {
-    return std::async(std::launch::async, [this, &system, &data]() { return this->runInternal(system, data); });
+    return system.getThreadPool().post([this, &system, &data]() { return this->runInternal(system, data); });
+}
+
+WorkerPool::~WorkerPool() {
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        stopping = true;
+    }
+    wake.notify_all();
+    for (auto &t : threads) t.join();
+}
+
+size_t WorkerPool::threadCount() {
+    std::lock_guard<std::mutex> lock(mutex);
+    return threads.size();
+}
+
+void WorkerPool::enqueue(std::function<void()> fn) {
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        queue.push_back(std::move(fn));
+        // more queued tasks than idle workers to take them: one more thread (every queued task is guaranteed a worker
+        // without waiting for a running -- possibly blocked -- task to end)
+        if (queue.size() > idle) threads.emplace_back([this]() { work(); });
+    }
+    wake.notify_one();
+}
+
+void WorkerPool::work() {
+    std::unique_lock<std::mutex> lock(mutex);
+    for (;;) {
+        while (queue.empty() && !stopping) {
+            ++idle;
+            wake.wait(lock);
+            --idle;
+        }
+        if (queue.empty()) return;   // stopping and drained
+        std::function<void()> fn = std::move(queue.front());
+        queue.pop_front();
+        lock.unlock();
+        fn();   // packaged_task: exceptions end up in the future
+        fn = nullptr;
+        lock.lock();
+    }
 }
 
 std::shared_ptr<SystemRunData> SystemRunData::getRelativeRun(const int8_t offset) {
@@ -26,8 +69,9 @@ size_t concurrentRunLimit() {
     return n > 0 ? (size_t)std::min(n, 64L) : (size_t)CARTSLAM_CONCURRENT_RUN_LIMIT;
 }
 
-System::System(std::shared_ptr<DataSource> dataSource, size_t runRetention, size_t concurrentRunLimit)
-    : runRetention(runRetention), concurrentRunLimit(concurrentRunLimit), dataSource(dataSource) {}
+System::System(std::shared_ptr<DataSource> dataSource, size_t runRetention, size_t concurrentRunLimit, size_t workerThreads)
+    : runRetention(runRetention), concurrentRunLimit(concurrentRunLimit), dataSource(dataSource),
+      threadPool(workerThreads ? workerThreads : 16 * concurrentRunLimit) {}
 
 System::~System() {
     std::unique_lock<std::mutex> lock(runMutex);
@@ -69,7 +113,7 @@ std::future<void> System::run() {
         ++activeRuns;
     }
     auto mods = modules;
-    return std::async(std::launch::async, [this, run, mods]() {
+    return threadPool.post([this, run, mods]() {
         auto frameTiming = timing::initTiming("Frame", run->id);  // cartslam.cpp:245-251
         timing::startTiming(frameTiming);
         std::exception_ptr first;
@@ -77,7 +121,7 @@ std::future<void> System::run() {
         for (const auto &m : mods) {
             // every module gets its own waiter: dependencies first (cartslam.cpp:96-167), then the module, then the
             // returned (key, ptr) pairs go onto the frame's blackboard (cartslam.cpp:279-301)
-            done.push_back(std::async(std::launch::async, [this, run, m]() {
+            done.push_back(threadPool.post([this, run, m]() {
                 auto moduleTiming = timing::initTiming(m->name, run->id);  // cartslam.cpp:259-262: init before the dependency wait
                 struct Finished {   // the module hears about the end of this frame on every way out, exceptions included
                     SystemModule &m; uint32_t id;
