@@ -143,7 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
-    ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (default: on for 8 paths, off for 4, where it measures slower)")
+    ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (default: on, except at D=64 / 4 paths where it measures even)")
+    ap.add_argument("--deferred", action="store_true", help="two streams, the plane stages of batch i gated behind the aggregation of batch i+1 (StereoPipeline overlap=\"deferred\")")
     ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -191,7 +192,7 @@ def main():
         eng.set_chunk_frames(args.chunk)
     plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
     pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True,
-                          overlap=False if args.no_overlap else True if args.overlap else "auto")
+                          overlap=False if args.no_overlap else "deferred" if args.deferred else True if args.overlap else "auto")
     # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     n_distinct = min(B, 4)
     ls, rs = synth.make_batch(n_distinct, w, h, D, 4, first_frame=rank * n_distinct)
@@ -216,6 +217,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pipe.process_batch(left, right)
+    pipe.flush()   # deferred mode: the plane stages of the last batch belong to the timed region (no-op otherwise)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     stages, ncalls = eng.collect_timing()
@@ -264,6 +266,10 @@ def main():
             torch.cuda.current_stream().wait_event(uploaded.pop(i))
             o = pipe.process_batch(dl, dr)
             consumed[i % 3] = torch.cuda.current_stream().record_event()
+            download(o)
+        def download(o):
+            if o is None:   # deferred mode: the outputs come one call later (the last ones from flush())
+                return
             d2h.wait_event(o["done"]) if "done" in o else d2h.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(d2h):
                 if args.pcie_copy == "narrow":   # a few workgroups write straight into the pinned (device-mapped) host buffers
@@ -278,6 +284,7 @@ def main():
         n_pcie = max(4, min(args.steps, 20))
         for i in range(2, 2 + n_pcie):
             pcie_step(i)
+        download(pipe.flush())
         torch.cuda.synchronize()
         pcie = {"pairs_per_s": round(B * n_pcie / (time.perf_counter() - tp), 1), "steps": n_pcie,
                 "moved_per_pair": "2 x gray H2D (pinned), s16 disparity + u8 planes D2H",
@@ -353,7 +360,7 @@ def main():
                                     (1242, 375, 64, 4): "BASELINE.json configs[1]",
                                     (1920, 1080, 256, 8): "BASELINE.json configs[3]"}.get((w, h, D, P), "not a BASELINE.json configuration"),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}",
-                       "launch_plan": plan, "two_stream_pipelining": pipe.side is not None,
+                       "launch_plan": plan, "two_stream_pipelining": ("deferred" if pipe.deferred else True) if pipe.side is not None else False,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": roof_kernel,

@@ -113,7 +113,9 @@ class Engine:
         return st.value
 
     # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
-    def compute_disparity(self, left, right, out=None):
+    def compute_disparity(self, left, right, out=None, gated_stream=None):
+        """gated_stream (a torch.cuda.Stream): made to wait until this call's path aggregation has finished
+        (cart_compute_disparity_batch_gated); what the caller enqueues there afterwards runs beside the WTA, not the aggregation."""
         import torch
         ch = 3 if (left.dim() >= 3 and left.shape[-1] == 3 and left.shape[-2] == self.width
                    and left.shape[-3] == self.height) else 1
@@ -129,6 +131,10 @@ class Engine:
         if out is None:
             out = torch.empty(shape, dtype=torch.int16, device=left.device)
         _, op, os_, ofs = _geom(out, 1)
+        if gated_stream is not None:
+            self._check(self._lib.cart_compute_disparity_batch_gated(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs, _stream_ptr(),
+                                                                     C.c_void_p(gated_stream.cuda_stream)), "cart_compute_disparity_batch_gated")
+            return out
         self._check(self._lib.cart_compute_disparity_batch(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs,
                                                            _stream_ptr()), "cart_compute_disparity_batch")
         return out

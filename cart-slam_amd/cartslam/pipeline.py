@@ -128,11 +128,19 @@ class StereoPipeline:
         # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
         # order.  Outputs other than "disparity" are then produced on `self.side`: synchronise (or wait for
         # out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
-        # overlap="auto": only for 8-path engines.  Measured (profiles/tools/stream_priority.py, 16 pairs per step): 8 paths
-        # gain 2-8 % (D=128: 2.89 vs 3.15 ms), 4 paths LOSE 2-8 % (D=64: 1.23 vs 1.19 ms, D=128: 2.00 vs 1.85) -- their
-        # aggregation launch is bound by the W-step chain of the horizontal scans, which the side stream's kernels slow down.
+        # overlap="auto": on, except for D=64 / 4 paths.  Measured (profiles/tools/r02_deferred.sh, 16 pairs per step, ms per step
+        # one stream / side stream / deferred): D=128 P=8 3.13 / 3.02 / 3.07, D=256 P=4 3.30 / 3.08 / 3.09, D=128 P=4 2.06 /
+        # 1.90 / 1.96, 1920x1080 D=256 P=8 (4 pairs) 6.73 / 6.20 / 6.14, D=64 P=4 1.29 / 1.29 / 1.26 -- there the aggregation
+        # launch is bound by the W-step chain of the horizontal scans, which the side stream's kernels slow down by what they save.
+        # overlap="deferred": the plane stages of batch i are enqueued by the NEXT process_batch call (or flush()), on the
+        # side stream, gated behind the aggregation of batch i+1 (cart_compute_disparity_batch_gated): they then run beside
+        # the HBM-bound WTA of batch i+1 instead of beside its aggregation.  process_batch returns the outputs of the
+        # PREVIOUS batch (None on the first call); flush() returns those of the last one.  Never chosen by "auto" (it changes
+        # what process_batch returns); worth 1-3 % where the aggregation is latency-bound (D=64 / 4 paths, 1920x1080).
         if overlap == "auto":
-            overlap = engine.P == 8
+            overlap = not (engine.P == 4 and engine.D <= 64)
+        self.deferred = overlap == "deferred"
+        self._pending = None
         self.side = torch.cuda.Stream() if overlap else None
 
     def process_batch(self, left, right):
@@ -140,6 +148,11 @@ class StereoPipeline:
             return self._process_batch(left, right)
         import torch
         main = torch.cuda.current_stream()
+        if self.deferred:
+            disp = self.engine.compute_disparity(left, right, gated_stream=self.side)
+            out = self._finish_pending()
+            self._pending = (left, right, disp, main.record_event())
+            return out
         disp = self.engine.compute_disparity(left, right)
         self.side.wait_stream(main)
         disp.record_stream(self.side)
@@ -148,13 +161,34 @@ class StereoPipeline:
             out["done"] = self.side.record_event()
         return out
 
+    def _finish_pending(self):
+        if self._pending is None:
+            return None
+        left, right, disp, ready = self._pending
+        self._pending = None
+        self.side.wait_event(ready)   # the batch's disparity (long past when a later batch's gate is already in the queue)
+        for t in (left, right, disp):
+            t.record_stream(self.side)
+        import torch
+        with torch.cuda.stream(self.side):
+            out = self._process_batch(left, right, disp)
+            out["done"] = self.side.record_event()
+        return out
+
+    def flush(self):
+        """overlap="deferred": enqueue the plane stages of the batch that is still pending and return its outputs
+        (None when nothing is pending or in the other modes, whose process_batch has already returned everything)."""
+        return self._finish_pending() if self.deferred else None
+
     def process_sequence(self, left, right, n_total, root=0, channels=1, keys=("disparity", "planes")):
         """A sequence that lives on `root` ([n_total, H, W] gray or, with channels=3, [n_total, H, W, 3] BGR; None elsewhere): scatter the frames, run this rank's
         share as one batch, gather the named outputs back on `root` in sequence order (None on the other ranks).  With
         world == 1 this is process_batch.  Frame ids continue from the previous call like process_batch's."""
         import torch
+        if self.deferred and self._pending is not None:
+            raise ValueError("process_sequence returns the outputs of the frames it is given: flush() the pending batch first")
         if self.world == 1 and not self.always_exchange:
-            out = self.process_batch(left, right)
+            out = self._batch_now(left, right)
             torch.cuda.current_stream().wait_event(out["done"]) if "done" in out else None
             return {k: out[k] for k in keys}
         e = self.engine
@@ -162,10 +196,15 @@ class StereoPipeline:
         per_frame = (e.height, e.width) if channels == 1 else (e.height, e.width, 3)
         l = scatter_sequence(left, n_total, (per_frame, torch.uint8, dev), root, self.group)
         r = scatter_sequence(right, n_total, (per_frame, torch.uint8, dev), root, self.group)
-        out = self.process_batch(l, r)
+        out = self._batch_now(l, r)
         if "done" in out:
             torch.cuda.current_stream().wait_event(out["done"])
         return {k: gather_sequence(out[k], root, self.group) for k in keys}
+
+    def _batch_now(self, left, right):
+        """process_batch + (deferred mode) flush: the outputs of exactly these frames."""
+        out = self.process_batch(left, right)
+        return self.flush() if self.deferred else out
 
     def _process_batch(self, left, right, disp=None):
         """left/right: uint8 [n,h,w(,3)] on the GPU: this rank's n frames of a global batch of

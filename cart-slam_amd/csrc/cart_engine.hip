@@ -35,6 +35,7 @@ int fail(const std::string &msg) {
 
 struct Slot {
     bool busy = false;
+    hipEvent_t gate = nullptr;          // cart_compute_disparity_batch_gated: "aggregation of this lease has finished" (first slot, lazily created)
     hipEvent_t done = nullptr;          // recorded only on the FIRST slot of a lease ...
     int owner = -1;                     // ... every slot of the lease points at that slot
     hipStream_t last_stream = nullptr;
@@ -342,8 +343,10 @@ void cart_engine_destroy(cart_engine *e) {
                     e->pair_xch, e->pair_ticket, e->dev_status};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    for (auto &s : e->slots)
+    for (auto &s : e->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
+        if (s.gate) (void)hipEventDestroy(s.gate);
+    }
     for (auto &r : e->ring)
         for (auto &ev : r.ev)
             if (ev) (void)hipEventDestroy(ev);
@@ -481,7 +484,7 @@ struct FrameSet {
     }
 };
 
-int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int channels, void *stream_) {
+int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int channels, void *stream_, void *gated_ = nullptr) {
     if (!e) return fail("engine is NULL");
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
@@ -513,6 +516,14 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
+    hipStream_t gated = static_cast<hipStream_t>(gated_);
+    if (gated == stream) gated = nullptr;
+    if (gated && !e->slots[l.s0].gate && hipEventCreateWithFlags(&e->slots[l.s0].gate, hipEventDisableTiming) != hipSuccess) {
+        e->slots[l.s0].gate = nullptr;
+        release(l);
+        return fail("hipEventCreate failed");
+    }
+    hipError_t gate_err = hipSuccess;
     TimingRec *rec = nullptr;
     if (opt.timing) {
         std::lock_guard<std::mutex> lk(e->mu);
@@ -562,6 +573,10 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         AggArgs a = pairs ? e->agg_pairs : fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
+        if (gated && f0 + n >= n_frames) {   // last launch sequence of the call: the aggregation of every frame is behind this point
+            gate_err = hipEventRecord(e->slots[l.s0].gate, st);
+            if (gate_err == hipSuccess) gate_err = hipStreamWaitEvent(gated, e->slots[l.s0].gate, 0);
+        }
         STAGE("wta");
         if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq, n, st);
         else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
@@ -596,9 +611,22 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     hipError_t err = hipGetLastError();
     release(l);
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
+    if (gate_err != hipSuccess) return fail(std::string("gating the second stream failed: ") + hipGetErrorString(gate_err));
     return 0;
 }
 }  // namespace
+
+int cart_compute_disparity_batch_gated(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
+                                       size_t left_frame_stride, const uint8_t *right, size_t right_step,
+                                       size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
+                                       size_t out_frame_stride, void *stream, void *gated_stream) {
+    if (!left || !right || !out) return fail("NULL image pointer");
+    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
+    FrameSet fr{};
+    fr.left = left; fr.right = right; fr.left_fs = left_frame_stride; fr.right_fs = right_frame_stride; fr.out = out; fr.out_fs = out_frame_stride;
+    fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
+    return compute_disparity_impl(e, n_frames, fr, channels, stream, gated_stream);
+}
 
 int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
                                  size_t left_frame_stride, const uint8_t *right, size_t right_step,

@@ -118,6 +118,18 @@ int cart_compute_disparity_batch(cart_engine *engine, int n_frames,
                                  int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
                                  void *stream);
 
+/* cart_compute_disparity_batch + a gate for a second stream of the caller: `gated_stream` is made to wait (hipStreamWaitEvent)
+ * for the point of `stream` where this call's path aggregation has finished and its WTA is about to start.  Work the caller
+ * enqueues on `gated_stream` afterwards therefore runs beside the HBM-bound WTA / post stages of this batch instead of beside
+ * its aggregation, whose W-step horizontal scans are slowed by any neighbour (the batched driver puts the previous batch's
+ * plane stages there: cartslam/pipeline.py, overlap="deferred").  No reference counterpart (the reference runs one frame per
+ * stream, disparity.cu:56).  gated_stream == NULL or == stream: plain cart_compute_disparity_batch. */
+int cart_compute_disparity_batch_gated(cart_engine *engine, int n_frames,
+                                       const uint8_t *left, size_t left_step, size_t left_frame_stride,
+                                       const uint8_t *right, size_t right_step, size_t right_frame_stride,
+                                       int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
+                                       void *stream, void *gated_stream);
+
 /* The same for frames that live in separate allocations: left[f] / right[f] / out[f] are the device images of frame f
  * (host arrays of n_frames device pointers, read before the call returns; one step per image kind).  This is what a
  * module adapter uses to coalesce the frames that the reference's runtime enters concurrently -- up to 12 worker threads

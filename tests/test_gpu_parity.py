@@ -874,3 +874,66 @@ def test_resize_linear(torch_cuda, sw, sh, dw, dh, ch):
     assert got.shape == exp.shape and (got == exp).all(), f"{int((got != exp).sum())} samples differ, max |diff| {int(np.abs(got.astype(int) - exp.astype(int)).max())}"
     if (sw, sh) == (dw, dh):
         assert (got == img).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [4, 8])
+def test_deferred_overlap_gives_the_same_outputs(torch_cuda, P):
+    """StereoPipeline(overlap="deferred") -- the plane stages of batch i enqueued by the next call, on the side stream, gated
+    behind the aggregation of batch i+1 (cart_compute_disparity_batch_gated) -- returns, one call later, exactly what the
+    one-stream pipeline returns: five batches whose scenes differ, a parameter refresh in between (ids 1 and 31)."""
+    torch = torch_cuda
+    from cartslam.pipeline import StereoPipeline
+    w, h, D, B = 330, 120, 64, 8
+    batches = []
+    for k in range(5):
+        ls, rs = synth.make_batch(B, w, h, D if k % 2 == 0 else 40, 4, first_frame=B * k)
+        batches.append((dev(torch, ls), dev(torch, rs)))
+    results = {}
+    for mode in (False, "deferred"):
+        eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2 * B)
+        pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=mode)
+        outs = []
+        for l, r in batches:
+            o = pipe.process_batch(l, r)
+            if o is not None:
+                outs.append(o)
+        last = pipe.flush()
+        assert (last is None) == (mode is False)
+        if last is not None:
+            outs.append(last)
+        torch.cuda.synchronize()
+        assert len(outs) == len(batches)
+        results[mode] = [{k: o[k].cpu().numpy() for k in ("disparity", "planes", "ids", "n_components", "components", "params")} for o in outs]
+        eng.close()
+    for a, b in zip(results[False], results["deferred"]):
+        for k in a:
+            if k == "components":   # rows past a frame's component count are not written
+                for f in range(B):
+                    nc = min(int(a["n_components"][f]), a[k].shape[1])
+                    assert np.array_equal(a[k][f, :nc], b[k][f, :nc]), (k, f)
+            else:
+                assert np.array_equal(a[k], b[k]), k
+    # the frames really differ from batch to batch (otherwise a one-batch shift would go unnoticed)
+    assert not np.array_equal(results[False][0]["disparity"], results[False][1]["disparity"])
+
+
+@pytest.mark.gpu
+def test_gated_batch_call(torch_cuda):
+    """cart_compute_disparity_batch_gated: same bits as the plain call; a gated stream equal to the launch stream is the plain call;
+    work enqueued on the gated stream afterwards sees the finished aggregation of that call (it is ordered after it)."""
+    torch = torch_cuda
+    w, h, D, P, n = 200, 64, 64, 8, 4
+    ls, rs = synth.make_batch(n, w, h, D, 4)
+    L, R = dev(torch, ls), dev(torch, rs)
+    eng = make_engine(w, h, D, P, 4, inflight=2 * n)
+    ref = eng.compute_disparity(L, R).cpu().numpy()
+    side = torch.cuda.Stream()
+    got = eng.compute_disparity(L, R, gated_stream=side)
+    with torch.cuda.stream(side):
+        marker = torch.ones(1, device="cuda")   # runs once the gate opens
+    same = eng.compute_disparity(L, R, gated_stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert float(marker.item()) == 1.0
+    assert (got.cpu().numpy() == ref).all() and (same.cpu().numpy() == ref).all()
+    eng.close()
