@@ -145,10 +145,14 @@ class FrameCoalescer {
     size_t groups = 0, frames = 0;
 };
 
-// CARTSLAM_COALESCE = frame groups of one module allowed on the GPU at once (default 2); 0 = one launch sequence per frame
+// CARTSLAM_COALESCE = frame groups of one module allowed on the GPU at once; 0 = one launch sequence per frame.
+// Default 1: while a group is on the GPU the next one collects every frame that arrives, so the groups are as large as
+// the frames in flight allow (12 in flight: 5.6 frames per launch and 4.98 k pairs/s at D=128 / 8 paths, against 3.7 and
+// 4.58 k with two groups and 2.5 / 4.56 k with three -- profiles/tools/r02_coalesce.sh; a launch of 3 frames is far from
+// filling the chip, and two of them side by side do not make up for it).
 static int coalesceGroups() {
     const char *env = std::getenv("CARTSLAM_COALESCE");
-    return env ? std::atoi(env) : 2;
+    return env ? std::atoi(env) : 1;
 }
 static int coalesceMaxGroup() { return (int)std::min<size_t>(concurrentRunLimit(), 16); }  // 16 = frames per launch sequence
 
