@@ -8,6 +8,7 @@
 // D are DPP ops inside a 16-lane row; see the comments at each kernel.
 #include <type_traits>
 
+#include <cstdlib>
 #include "engine_internal.h"
 
 namespace cart_amd {
@@ -698,10 +699,30 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     AggArgs a = a_in;
     a.n_frames = n_frames;
     dim3 grid(a.blocks_per_frame * n_frames), block(64 * kAggWaves);
+    // A cap on the workgroups resident per CU, enforced with unused dynamic LDS: the others are dispatched as slots free
+    // up.  With everything resident at once (7 waves per SIMD fit) the CUs that hold the W-step horizontal scans end up
+    // with as many of the short vertical / diagonal scans as the others and finish last; with 3-4 workgroups per CU the
+    // dispatcher hands the short scans to whichever CU is free, the long scans keep most of their SIMD, and the census
+    // planes the directions re-read stay in L2.  Aggregate launch in ms, 7 resident / 5 / 4 / 3 / 2 (r02_agg_residency*.sh):
+    //   D=128 P=8          1.574 / 1.547 / 1.540 / 1.60 / 1.69      D=256 P=4 (3 directions) 1.215 / - / 1.19 / - / 1.23
+    //   1080p D=256 P=8    3.51  /  -    / 3.29  /  -   / 3.56      D=64 P=4   0.52-0.63 / 0.52-0.57 / - / 0.49-0.51 / 0.52
+    //   D=128 P=4          1.00-1.07 / - / 0.86 / 0.82 / -
+    // -> 4 per CU, 3 for launches of at most four directions at D <= 128 (their horizontal scans are half the work).  The
+    // exception is the 7-8 direction launch at D <= 128: beside the plane stages of the previous batch on the second stream
+    // (the bench's default) the cap costs a 16-frame launch 1 % (1.61-1.68 against 1.59-1.63 ms), so that one keeps
+    // everything resident; the frame loop's launches of ~6 frames gain 5 % from it (4.73-4.88 against 4.54-4.61 k pairs/s).
+    constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
+    const int resident = a.ndirs <= 4 ? (a.g.D <= 128 ? 3 : 4) : (a.g.D >= 256 || n_frames < 16 ? 4 : 0);
+    const int lpp = a.g.D / 16;
+    const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
+    size_t pad = resident ? kLdsPerCu / resident - kLdsGranule - static_lds : 0;
+#ifdef CART_EXPERIMENTS
+    if (const char *e = std::getenv("CART_AGG_DYNLDS")) pad = std::strtoul(e, nullptr, 0);
+#endif
     switch (a.g.D) {
-        case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(aggregate_kernel<16>, grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, pad, s, a); break;
+        case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, pad, s, a); break;
+        default: hipLaunchKernelGGL(aggregate_kernel<16>, grid, block, pad, s, a); break;
     }
 }
 
