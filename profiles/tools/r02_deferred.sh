@@ -5,5 +5,5 @@ run() { name=$1; shift; timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline 
   python3 -c 'import json,sys; d=json.loads(open(sys.argv[1]).read()); print(sys.argv[2], d["value"], d["ms_per_step"], d["config"]["two_stream_pipelining"], d["stages_ms_per_launch"])' $O/$name.json $name; }
 for cfg in "c2:" "c1:--disparities_64_--paths_4" "ref:--disparities_256_--paths_4" "d128p4:--disparities_128_--paths_4" "c3:--width_1920_--height_1080_--disparities_256_--batch_4"; do
   name=${cfg%%:*}; a=${cfg#*:}; a=${a//_/ }
-  for mode in --no-overlap --overlap --deferred; do run ${name}_${mode#--} $a $mode; done
+  for mode in no-overlap overlap deferred; do run ${name}_$mode $a --$mode; done
 done
