@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
-    ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (default: on, except at D=64 / 4 paths where it measures even)")
+    ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (the default)")
     ap.add_argument("--deferred", action="store_true", help="two streams, the plane stages of batch i gated behind the aggregation of batch i+1 (StereoPipeline overlap=\"deferred\")")
     ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")

@@ -128,17 +128,18 @@ class StereoPipeline:
         # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
         # order.  Outputs other than "disparity" are then produced on `self.side`: synchronise (or wait for
         # out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
-        # overlap="auto": on, except for D=64 / 4 paths.  Measured (profiles/tools/r02_deferred.sh, 16 pairs per step, ms per step
-        # one stream / side stream / deferred): D=128 P=8 3.13 / 3.02 / 3.07, D=256 P=4 3.30 / 3.08 / 3.09, D=128 P=4 2.06 /
-        # 1.90 / 1.96, 1920x1080 D=256 P=8 (4 pairs) 6.73 / 6.20 / 6.14, D=64 P=4 1.29 / 1.29 / 1.26 -- there the aggregation
-        # launch is bound by the W-step chain of the horizontal scans, which the side stream's kernels slow down by what they save.
+        # overlap="auto" = on.  Measured (profiles/tools/r02_deferred.sh, 16 pairs per step, ms per step one stream / side stream /
+        # deferred, after the residency cap of the aggregation launch): D=128 P=8 3.20 / 3.02 / 3.10, D=256 P=4 3.07 / 2.98 /
+        # 3.08, D=128 P=4 1.80 / 1.74 / 1.76, 1920x1080 D=256 P=8 (4 pairs) 6.13 / 5.99 / 6.00, D=64 P=4 1.28 / 1.24 / 1.20.
+        # (Before that cap the 4-path engines lost 2-8 % to the side stream: their aggregation launch is bound by the W-step
+        # chain of the horizontal scans, which the side stream's kernels slow down.)
         # overlap="deferred": the plane stages of batch i are enqueued by the NEXT process_batch call (or flush()), on the
         # side stream, gated behind the aggregation of batch i+1 (cart_compute_disparity_batch_gated): they then run beside
         # the HBM-bound WTA of batch i+1 instead of beside its aggregation.  process_batch returns the outputs of the
         # PREVIOUS batch (None on the first call); flush() returns those of the last one.  Never chosen by "auto" (it changes
-        # what process_batch returns); worth 1-3 % where the aggregation is latency-bound (D=64 / 4 paths, 1920x1080).
+        # what process_batch returns); worth 3 % more than the plain side stream where the aggregation is latency-bound (D=64 / 4 paths: 13.4 k pairs/s).
         if overlap == "auto":
-            overlap = not (engine.P == 4 and engine.D <= 64)
+            overlap = True
         self.deferred = overlap == "deferred"
         self._pending = None
         self.side = torch.cuda.Stream() if overlap else None
