@@ -707,12 +707,15 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     //   D=128 P=8          1.574 / 1.547 / 1.540 / 1.60 / 1.69      D=256 P=4 (3 directions) 1.215 / - / 1.19 / - / 1.23
     //   1080p D=256 P=8    3.51  /  -    / 3.29  /  -   / 3.56      D=64 P=4   0.52-0.63 / 0.52-0.57 / - / 0.49-0.51 / 0.52
     //   D=128 P=4          1.00-1.07 / - / 0.86 / 0.82 / -
-    // -> 4 per CU, 3 for launches of at most four directions at D <= 128 (their horizontal scans are half the work).  The
+    // -> 4 per CU, 3 (D=128) or 2 (D=64) for launches of at most four directions (their horizontal scans are half the work).  The
     // exception is the 7-8 direction launch at D <= 128: beside the plane stages of the previous batch on the second stream
     // (the bench's default) the cap costs a 16-frame launch 1 % (1.61-1.68 against 1.59-1.63 ms), so that one keeps
     // everything resident; the frame loop's launches of ~6 frames gain 5 % from it (4.73-4.88 against 4.54-4.61 k pairs/s).
     constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
-    const int resident = a.ndirs <= 4 ? (a.g.D <= 128 ? 3 : 4) : (a.g.D >= 256 || n_frames < 16 ? 4 : 0);
+    // With the second stream on (the default) D=64 P=4 is faster still with two per CU: 1.04-1.10 against 1.13-1.18 ms per
+    // step (r02_agg_residency6.sh; D=128 P=4: 1.72-1.77 with two, 1.68-1.75 with three).  Smaller workgroups are slower (two
+    // waves or one: the headline's launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64 (r02_agg_waves.sh).
+    const int resident = (a.ndirs <= 4 ? (a.g.D <= 64 ? 2 : a.g.D <= 128 ? 3 : 4) : (a.g.D >= 256 || n_frames < 16 ? 4 : 0)) * 4 / kAggWaves;   // counted in 4-wave workgroups
     const int lpp = a.g.D / 16;
     const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
     size_t pad = resident ? kLdsPerCu / resident - kLdsGranule - static_lds : 0;
