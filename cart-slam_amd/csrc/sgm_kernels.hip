@@ -8,6 +8,7 @@
 // D are DPP ops inside a 16-lane row; see the comments at each kernel.
 #include <type_traits>
 
+#include <algorithm>
 #include <cstdlib>
 #include "engine_internal.h"
 
@@ -718,7 +719,8 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     const int resident = (a.ndirs <= 4 ? (a.g.D <= 64 ? 2 : a.g.D <= 128 ? 3 : 4) : (a.g.D >= 256 || n_frames < 16 ? 4 : 0)) * 4 / kAggWaves;   // counted in 4-wave workgroups
     const int lpp = a.g.D / 16;
     const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
-    size_t pad = resident ? kLdsPerCu / resident - kLdsGranule - static_lds : 0;
+    // (never more than 64 KB per workgroup in all, the limit that needs no opt-in: two of those per CU are still two)
+    size_t pad = resident ? std::min<size_t>(kLdsPerCu / resident - kLdsGranule, 64 * 1024) - static_lds : 0;
 #ifdef CART_EXPERIMENTS
     if (const char *e = std::getenv("CART_AGG_DYNLDS")) pad = std::strtoul(e, nullptr, 0);
 #endif
