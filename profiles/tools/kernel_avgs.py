@@ -1,4 +1,6 @@
 """Prints the per-kernel average duration from a rocprofv3 *_kernel_stats.csv (names shortened)."""
+import signal
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # quiet under "| head"
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Name"].split("(")[0][-40:]
