@@ -1221,7 +1221,10 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
-    const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
+    size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
+#ifdef CART_EXPERIMENTS
+    if (const char *e = std::getenv("CART_WTA_DYNLDS")) lds += std::strtoul(e, nullptr, 0);   // residency experiments (unused LDS)
+#endif
     WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, uniq, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
     switch (g.D) {
         case 64: hipLaunchKernelGGL((wta_kernel<4, false>), grid, block, lds, s, a); break;
