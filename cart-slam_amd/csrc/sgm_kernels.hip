@@ -1015,6 +1015,18 @@ void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *sl
 // the two-kernel WTA did not move (2.03 ms at D = 256 with or without).
 __host__ __device__ constexpr int rv_slot(int i) { return i + (i >> 4); }
 __host__ __device__ constexpr int rv_size(int n) { return ((n + (n >> 4) + 1) + 3) & ~3; }   // slots for n entries (+ a spare), multiple of 4
+// Slots of one right-view row of a fused-sweep block (cols + D - 1 entries + a spare, padded or not), a multiple of 8: in
+// the partial buffer a slot is ONE u16 -- (S << log2(cols)) | (d mod cols), 0xffff = empty -- and a burst packs 8 of them
+// per lane.  For entry e of a block the candidates are the block's columns xl = 0..cols-1 with d = D-1-e + xl, so d mod cols
+// identifies the column and rv_key32 gives the (S << 16 | d) key back; S <= 8 * 255 leaves 5 bits for cols = 32.
+__host__ __device__ constexpr int rv_row_slots(int cols, int D, bool padded) { return ((padded ? rv_size(cols + D - 1) : cols + D) + 7) & ~7; }
+__host__ __device__ constexpr uint32_t rv_key16(uint32_t key32, int cols) {   // cols = 16 or 32; 0xffffffff -> 0xffff
+    return ((((key32 >> 16) << (cols == 32 ? 5 : 4)) | (key32 & (uint32_t)(cols - 1))) & 0xffffu);
+}
+__host__ __device__ constexpr uint32_t rv_key32(uint32_t key16, int e, int cols, int D) {   // key16 != 0xffff
+    const int sh = cols == 32 ? 5 : 4, base = D - 1 - e;
+    return ((key16 >> sh) << 16) | (uint32_t)(base + (((int)(key16 & (uint32_t)(cols - 1)) - base) & (cols - 1)));
+}
 // slot of entry base - j for j in [0, 15], from s0 = rv_slot(base) and b4 = base & 15 (base >= 15)
 __device__ __forceinline__ int rv_slot_below(int s0, int b4, int j) { return s0 - j - (j > b4 ? 1 : 0); }
 
@@ -1289,7 +1301,7 @@ struct FusedArgs {
     const uint32_t *cen_l, *cen_r;
     const uint8_t *slabs;
     uint16_t *wta_l;
-    uint32_t *partial;   // [frame][y][block][NR + 1] right-view minima of every block (last entry: unused sink)
+    uint32_t *partial;   // [frame][block][sweep step][rv_row_slots] u16 right-view minima of every block (rv_key16; last slot of a row: unused sink)
     Geometry g;
     float uniq;
 };
@@ -1310,7 +1322,9 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = WPB_, NT = 64 * WPB;
     constexpr bool RVPAD = LPP == 16 && NP == 4;   // see rv_slot
-    constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = RVPAD ? rv_size(NR) : NR + 1;   // slots per row, the last one a spare
+    constexpr int P = WN::P, D = WN::D, COLS = WPB * P, NR = COLS + D - 1, NRP = rv_row_slots(COLS, D, RVPAD);   // slots per row, the last one a spare
+    static_assert(COLS == 16 || COLS == 32, "rv_key16 packs the column into 4 or 5 bits");
+    static_assert((RVPAD ? rv_slot(NR - 1) : NR - 1) < NRP - 1, "the row's last slot is a spare");
     __shared__ uint32_t s_win[WPB][WN::BUF];
     constexpr int DP = D + 8;                    // LDS pitch of a pixel's sum row (16 B of padding against bank conflicts)
     __shared__ __attribute__((aligned(16))) uint16_t s_tile[1][COLS * DP];
@@ -1491,7 +1505,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     // Burst of the buffered rows (LDS row r holds image row ytop + nrows-1-r).  Stores inside the row loop would sit
     // between the prefetch loads in vmcnt's in-order retirement; the row loop itself is branch-free and holds loads only.
     // Burst of the buffered rows.  It is branch-free with a fixed number of stores per lane: the partial buffer is laid out
-    // [frame][block][sweep step][NRP] (rows padded to a multiple of RB), so a burst is one linear copy of RB*NRP dwords
+    // [frame][block][sweep step][NRP u16 keys] (rows padded to a multiple of RB), so a burst is one linear copy of RB*NRP slots
     // (rows past the last one land in the padding), and the few left-disparity stores of dead lanes go to a sink entry.
     // With a data-dependent store count (or addresses that spill) the compiler cannot count the VMEM operations between
     // the prefetches issued before the burst and their use after it and waits for everything, including the
@@ -1499,7 +1513,8 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     auto flush = [&](int t0, int nrows) {   // LDS row r = sweep step t0 + r = image row h-1-t0-r
         if (CART_FUSED_ABLATE & 512) return;   // timing experiment: no burst
         if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();   // 2048: burst without its two barriers
-        uint32_t *pbase = a.partial + (((size_t)frame * nblk + blk) * (size_t)hpad + t0) * NRP;
+        // partial rows hold u16 keys (rv_key16): NRP / 2 dwords per row
+        uint32_t *pbase = a.partial + (((size_t)frame * nblk + blk) * (size_t)hpad + t0) * (NRP / 2);
 #pragma unroll
         for (int i0 = 0; i0 < RB * COLS; i0 += NT) {
             const int i = min(i0 + (int)threadIdx.x, RB * COLS - 1);
@@ -1517,23 +1532,25 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
             }
             const bool live = r < nrows && x0 + c < g.w && i0 + (int)threadIdx.x < RB * COLS;
             uint16_t *dst = live ? a.wta_l + (size_t)frame * g.npx + (size_t)(g.h - 1 - t0 - r) * g.w + x0 + c
-                                 : reinterpret_cast<uint16_t *>(pbase + NRP - 1);   // the spare slot of the chunk's first row
+                                 : reinterpret_cast<uint16_t *>(pbase) + NRP - 1;   // the spare slot of the chunk's first row
             if (!(CART_FUSED_ABLATE & 16)) *dst = (uint16_t)out;
         }
-        static_assert(RB * NRP % 4 == 0, "the right-view rows are copied 16 bytes per lane");
+        static_assert(RB * NRP % 8 == 0, "a lane packs eight right-view slots into one 16-byte store");
 #pragma unroll
-        for (int i0 = 0; i0 < RB * NRP / 4; i0 += NT) {
+        for (int i0 = 0; i0 < RB * NRP / 8; i0 += NT) {
             const int i = i0 + (int)threadIdx.x;
-            const bool live = i < RB * NRP / 4;   // excess lanes store ones into the last (never used) row of the block's area
-            v4u v = v4u{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const bool live = i < RB * NRP / 8;   // excess lanes store ones into the last (never used) row of the block's area
+            const v4u ones = v4u{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            v4u v = ones;
             if (live) {
-                v4u *src = reinterpret_cast<v4u *>(&s_rmin[0][0]) + i;
-                const v4u t = *src;
-                *src = v;
-                v = t;
+                v4u *src = reinterpret_cast<v4u *>(&s_rmin[0][0]) + 2 * i;
+                const v4u t0v = src[0], t1v = src[1];
+                src[0] = ones; src[1] = ones;
+                v = v4u{rv_key16(t0v.x, COLS) | (rv_key16(t0v.y, COLS) << 16), rv_key16(t0v.z, COLS) | (rv_key16(t0v.w, COLS) << 16),
+                        rv_key16(t1v.x, COLS) | (rv_key16(t1v.y, COLS) << 16), rv_key16(t1v.z, COLS) | (rv_key16(t1v.w, COLS) << 16)};
             }
             v4u *dst = live ? reinterpret_cast<v4u *>(pbase) + i
-                            : reinterpret_cast<v4u *>(a.partial + (((size_t)frame * nblk + blk + 1) * (size_t)hpad) * NRP) - 1;
+                            : reinterpret_cast<v4u *>(a.partial + (((size_t)frame * nblk + blk + 1) * (size_t)hpad) * (NRP / 2)) - 1;
             if (!(CART_FUSED_ABLATE & 8)) *dst = v;
         }
         if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();
@@ -1574,16 +1591,18 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
 }
 
 // right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p.
-// partial = [frame][block][sweep step t = h-1-y][cols + D] (rows padded, see wta_fused_kernel's flush)
+// partial = [frame][block][sweep step t = h-1-y][rv_row_slots u16 keys] (rows padded, see wta_fused_kernel's flush)
 __global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk, int padded) {
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
     if (p >= w || y >= h) return;
-    const int nrp = padded ? rv_size(cols + D - 1) : cols + D, hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
+    const int nrp = rv_row_slots(cols, D, padded != 0), hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
+    const uint16_t *keys = reinterpret_cast<const uint16_t *>(partial);
     const int b0 = p / cols, b1 = min((p + D - 1) / cols, nblk - 1);
     uint32_t best = 0xffffffffu;
     for (int b = b0; b <= b1; ++b) {
         const int e = p - (b * cols - (D - 1));
-        best = min(best, partial[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (padded ? rv_slot(e) : e)]);
+        const uint32_t k = keys[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (padded ? rv_slot(e) : e)];
+        if (k != 0xffffu) best = min(best, rv_key32(k, e, cols, D));
     }
     right_pk[((size_t)frame * h + y) * w + p] = best;
 }
@@ -1593,7 +1612,7 @@ inline bool fused_rv_padded(const Geometry &g) { return g.D >= 256 && g.P == 4; 
 size_t wta_fused_partial_elems(const Geometry &g) {
     const int cols = fused_waves_for(g) * (64 / (g.D / 16));
     const int hpad = (g.h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
-    return (size_t)hpad * ((g.w + cols - 1) / cols) * (fused_rv_padded(g) ? rv_size(cols + g.D - 1) : cols + g.D);
+    return (size_t)hpad * ((g.w + cols - 1) / cols) * (rv_row_slots(cols, g.D, fused_rv_padded(g)) / 2);   // u32 elements of u16 keys
 }
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
