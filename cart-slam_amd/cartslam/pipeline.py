@@ -103,7 +103,7 @@ class StereoPipeline:
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
                  with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096, keep_hists=False,
-                 always_exchange=False):
+                 always_exchange=False, split_stages=False):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
@@ -126,8 +126,8 @@ class StereoPipeline:
         # overlap=True: the plane stages of batch i run on a side stream while the main stream already computes the
         # disparity of batch i+1 (the plane stages are short, latency-bound launches that leave the GPU mostly idle).
         # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
-        # order.  Outputs other than "disparity" are then produced on `self.side`: synchronise (or wait for
-        # out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
+        # order.  The outputs are then produced on `self.side` ("disparity" too when split_stages is on): synchronise (or
+        # wait for out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
         # overlap="auto" = on.  Measured (profiles/tools/r02_deferred.sh, 16 pairs per step, ms per step one stream / side stream /
         # deferred, after the residency cap of the aggregation launch): D=128 P=8 3.20 / 3.02 / 3.10, D=256 P=4 3.07 / 2.98 /
         # 3.08, D=128 P=4 1.80 / 1.74 / 1.76, 1920x1080 D=256 P=8 (4 pairs) 6.13 / 5.99 / 6.00, D=64 P=4 1.28 / 1.24 / 1.20.
@@ -143,12 +143,34 @@ class StereoPipeline:
         self.deferred = overlap == "deferred"
         self._pending = None
         self.side = torch.cuda.Stream() if overlap else None
+        # split_stages (with a side stream, not deferred): the main stream carries only aggregation + WTA; the stages after the
+        # WTA join the plane stages on the side stream, and -- when the caller says where the inputs are complete
+        # (process_batch(..., inputs_ready=event)) -- the census of batch i+1 runs on a third stream beside the WTA of batch i
+        # (cart_compute_disparity_batch_streams).  Off by default: measured (profiles/tools/r02_split.sh, three A/B pairs per
+        # configuration) it gains 1-4 % at D=64 / 4 paths and loses 1-3 % at D=128 / 8 paths, D=256 / 4 paths and 1920x1080 --
+        # the short kernels cost the two long launches more beside them than they cost in front of them.
+        self.split_stages = bool(overlap) and not self.deferred and split_stages
+        self.pre = torch.cuda.Stream() if self.split_stages else None
 
-    def process_batch(self, left, right):
+    def process_batch(self, left, right, inputs_ready=None):
+        """inputs_ready: a torch.cuda.Event after which `left` / `right` are complete (the upload's event, or one recorded
+        when resident inputs were written).  Without it the inputs are taken to be complete on the current stream only."""
         if self.side is None:
             return self._process_batch(left, right)
         import torch
         main = torch.cuda.current_stream()
+        if self.split_stages:
+            census_stream = None
+            if inputs_ready is not None:
+                self.pre.wait_event(inputs_ready)
+                left.record_stream(self.pre); right.record_stream(self.pre)
+                census_stream = self.pre
+            disp = self.engine.compute_disparity(left, right, census_stream=census_stream, tail_stream=self.side)
+            disp.record_stream(self.side)
+            with torch.cuda.stream(self.side):   # post + interpolate of this batch are already queued there
+                out = self._process_batch(left, right, disp)
+                out["done"] = self.side.record_event()
+            return out
         if self.deferred:
             disp = self.engine.compute_disparity(left, right, gated_stream=self.side)
             out = self._finish_pending()

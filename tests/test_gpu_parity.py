@@ -890,30 +890,36 @@ def test_deferred_overlap_gives_the_same_outputs(torch_cuda, P):
         ls, rs = synth.make_batch(B, w, h, D if k % 2 == 0 else 40, 4, first_frame=B * k)
         batches.append((dev(torch, ls), dev(torch, rs)))
     results = {}
-    for mode in (False, "deferred"):
+    torch.cuda.synchronize()
+    ready = torch.cuda.current_stream().record_event()   # the inputs are complete from here on
+    # "split": post stages on the side stream; "split_ready": the census on a third stream as well (the inputs' event given)
+    for mode in (False, "deferred", "split", "split_ready"):
         eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2 * B)
-        pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=mode)
+        pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=True if str(mode).startswith("split") else mode,
+                              split_stages=str(mode).startswith("split"))
+        assert pipe.split_stages == str(mode).startswith("split")
         outs = []
         for l, r in batches:
-            o = pipe.process_batch(l, r)
+            o = pipe.process_batch(l, r, inputs_ready=ready if mode == "split_ready" else None)
             if o is not None:
                 outs.append(o)
         last = pipe.flush()
-        assert (last is None) == (mode is False)
+        assert (last is None) == (mode != "deferred")
         if last is not None:
             outs.append(last)
         torch.cuda.synchronize()
         assert len(outs) == len(batches)
         results[mode] = [{k: o[k].cpu().numpy() for k in ("disparity", "planes", "ids", "n_components", "components", "params")} for o in outs]
         eng.close()
-    for a, b in zip(results[False], results["deferred"]):
+    for mode in ("deferred", "split", "split_ready"):
+      for a, b in zip(results[False], results[mode]):
         for k in a:
             if k == "components":   # rows past a frame's component count are not written
                 for f in range(B):
                     nc = min(int(a["n_components"][f]), a[k].shape[1])
-                    assert np.array_equal(a[k][f, :nc], b[k][f, :nc]), (k, f)
+                    assert np.array_equal(a[k][f, :nc], b[k][f, :nc]), (mode, k, f)
             else:
-                assert np.array_equal(a[k], b[k]), k
+                assert np.array_equal(a[k], b[k]), (mode, k)
     # the frames really differ from batch to batch (otherwise a one-batch shift would go unnoticed)
     assert not np.array_equal(results[False][0]["disparity"], results[False][1]["disparity"])
 
@@ -933,7 +939,16 @@ def test_gated_batch_call(torch_cuda):
     with torch.cuda.stream(side):
         marker = torch.ones(1, device="cuda")   # runs once the gate opens
     same = eng.compute_disparity(L, R, gated_stream=torch.cuda.current_stream())
+    # cart_compute_disparity_batch_streams: census on a third stream, post stages on a second one, three calls back to back
+    pre, tail = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    spread = []
+    for k in range(3):
+        spread.append(eng.compute_disparity(L if k != 1 else R, R if k != 1 else L, census_stream=pre, tail_stream=tail, gated_stream=side))
+    swapped = eng.compute_disparity(R, L)
     torch.cuda.synchronize()
     assert float(marker.item()) == 1.0
     assert (got.cpu().numpy() == ref).all() and (same.cpu().numpy() == ref).all()
+    assert (spread[0].cpu().numpy() == ref).all() and (spread[2].cpu().numpy() == ref).all()
+    assert (spread[1].cpu().numpy() == swapped.cpu().numpy()).all()
     eng.close()
