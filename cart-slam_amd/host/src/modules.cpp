@@ -103,14 +103,16 @@ class FrameCoalescer {
    public:
     using Compatible = std::function<bool(const Request &, const Request &)>;
     using RunGroup = std::function<void(const std::vector<Request *> &)>;   // enqueue + wait; throws on failure
-    FrameCoalescer(int maxGroup, int maxOutstanding, Compatible compatible, RunGroup runGroup)
-        : maxGroup(maxGroup), maxOutstanding(maxOutstanding), compatible(std::move(compatible)), runGroup(std::move(runGroup)) {}
+    FrameCoalescer(int maxGroup, int maxOutstanding, Compatible compatible, RunGroup runGroup, int minAhead = 1)
+        : maxGroup(maxGroup), maxOutstanding(maxOutstanding), minAhead(minAhead), compatible(std::move(compatible)), runGroup(std::move(runGroup)) {}
 
     void run(Request &rq) {
         std::unique_lock<std::mutex> lock(mutex);
         pending.push_back(&rq);
         while (!rq.done) {
-            if (!rq.queued || outstanding >= maxOutstanding) { cv.wait(lock); continue; }
+            // a group is dispatched at once while the GPU has none of this module's; a further one (queued behind it, so that
+            // the GPU does not idle through the host round trip between two groups) only when `minAhead` requests have gathered
+            if (!rq.queued || outstanding >= maxOutstanding || (outstanding > 0 && (int)pending.size() < minAhead)) { cv.wait(lock); continue; }
             // leader: this request + every queued one with the same image layout, oldest first
             std::vector<Request *> group{&rq}, rest;
             for (Request *q : pending) {
@@ -135,7 +137,7 @@ class FrameCoalescer {
     double meanGroup() { std::lock_guard<std::mutex> lock(mutex); return groups ? (double)frames / groups : 0.0; }
 
    private:
-    const int maxGroup, maxOutstanding;
+    const int maxGroup, maxOutstanding, minAhead;
     const Compatible compatible;
     const RunGroup runGroup;
     std::mutex mutex;
@@ -155,6 +157,11 @@ static int coalesceGroups() {
     return env ? std::atoi(env) : 1;
 }
 static int coalesceMaxGroup() { return (int)std::min<size_t>(concurrentRunLimit(), 16); }  // 16 = frames per launch sequence
+// CARTSLAM_COALESCE_AHEAD = requests that must have gathered before a group is queued behind a running one (with CARTSLAM_COALESCE >= 2)
+static int coalesceMinAhead() {
+    const char *env = std::getenv("CARTSLAM_COALESCE_AHEAD");
+    return env ? std::max(1, std::atoi(env)) : std::max(2, (int)std::min<size_t>(concurrentRunLimit(), 32) / 2);
+}
 
 // ---------------------------------------------------------------- disparity (disparity.cu:49-80)
 struct DisparityRequest : CoalescedRequest {
@@ -188,7 +195,8 @@ ImageDisparityModule::ImageDisparityModule(const Size imageRes, int minDisparity
                                                  outs.data(), rq.outStep, stream.s) != 0)
                     eng->fail("cart_compute_disparity_multi");
                 stream.wait();  // stream.waitForCompletion(), disparity.cu:77
-            });
+            },
+            coalesceMinAhead());
     }
 }
 
@@ -348,7 +356,8 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
                         if (cart_plane_classify_multi(eng->get(), (int)group.size(), derivsIn.data(), rq.derivativesStep, &cp, 0, labels.data(), rq.planesStep, stream.s) != 0)
                             eng->fail("cart_plane_classify_multi");
                         stream.wait();
-                    });
+                    },
+                    coalesceMinAhead());
             }
         }
         auto planes = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_8UC1);
