@@ -946,7 +946,12 @@ def test_gated_batch_call(torch_cuda):
     for k in range(3):
         spread.append(eng.compute_disparity(L if k != 1 else R, R if k != 1 else L, census_stream=pre, tail_stream=tail, gated_stream=side))
     swapped = eng.compute_disparity(R, L)
+    # several launch sequences inside one call (2 frames each): every one hands over census -> main -> tail through its own markers
+    eng.set_chunk_frames(2)
+    chunked = eng.compute_disparity(L, R, census_stream=pre, tail_stream=tail)
+    eng.set_chunk_frames(16)
     torch.cuda.synchronize()
+    assert (chunked.cpu().numpy() == ref).all()
     assert float(marker.item()) == 1.0
     assert (got.cpu().numpy() == ref).all() and (same.cpu().numpy() == ref).all()
     assert (spread[0].cpu().numpy() == ref).all() and (spread[2].cpu().numpy() == ref).all()
