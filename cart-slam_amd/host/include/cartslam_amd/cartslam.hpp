@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -111,6 +112,8 @@ class System : public DataContainer {
     bool verifiedDependencies = false;
     uint32_t runId = 0;
     size_t activeRuns = 0;
+    std::set<uint32_t> activeIds;   // frames whose modules are still running (guarded by runMutex)
+    uint32_t maxBackOffset = 0;     // largest |runOffset| any module asks for (verifyDependencies)
     std::shared_ptr<DataSource> dataSource;
     std::vector<std::shared_ptr<SystemModule>> modules;
     std::vector<std::shared_ptr<SystemRunData>> runs;

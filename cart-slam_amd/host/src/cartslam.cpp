@@ -92,8 +92,10 @@ void System::verifyDependencies() {
     for (const auto &m : modules)
         for (const auto &k : m->getProvidedData()) provided[k] = true;
     for (const auto &m : modules)
-        for (const auto &d : m->getRequiredData())
+        for (const auto &d : m->getRequiredData()) {
             if (!d.optional && !provided.count(d.name)) throw std::invalid_argument("Module " + m->name + " requires \"" + d.name + "\" but no module provides it");
+            if (d.runOffset < 0) maxBackOffset = std::max<uint32_t>(maxBackOffset, (uint32_t)(-(int)d.runOffset));
+        }
     verifiedDependencies = true;
 }
 
@@ -109,7 +111,12 @@ std::future<void> System::run() {
         timing::endTiming(sourceTiming);
         run = std::make_shared<SystemRunData>(++runId, this, element);
         runs.push_back(run);
-        if (runs.size() > runRetention) runs.erase(runs.begin());  // cartslam.cpp:202-205
+        activeIds.insert(run->id);
+        // cartslam.cpp:202-205 drops the oldest run as soon as the ring is full.  A frame that is still running may need that run
+        // (its own blackboard, or the earlier frames its modules depend on): with 12 frames in flight a single slow frame is
+        // overtaken by 32 newer ones in a few milliseconds.  The ring therefore keeps what the oldest active frame can still ask for.
+        const uint32_t oldestActive = *activeIds.begin();
+        while (runs.size() > runRetention && runs.front()->id + maxBackOffset < oldestActive) runs.erase(runs.begin());
         ++activeRuns;
     }
     auto mods = modules;
@@ -148,6 +155,7 @@ std::future<void> System::run() {
         {
             std::unique_lock<std::mutex> lock(runMutex);
             --activeRuns;
+            activeIds.erase(run->id);
         }
         runCondition.notify_all();
         if (first) std::rethrow_exception(first);

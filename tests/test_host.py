@@ -56,6 +56,16 @@ def test_exe_exists():
     assert os.path.exists(EXE), "host executable not built (make -C cart-slam_amd)"
 
 
+def test_runtime_without_gpu():
+    """System / worker pool / blackboard / cross-frame dependencies / retention ring with dummy modules (host/tests/runtime_test.cpp):
+    400 frames, 12 in flight, consumers listed before their providers, one module that throws on one frame."""
+    exe = os.path.join(os.path.dirname(EXE), "runtime_test")
+    assert os.path.exists(exe), "runtime_test not built (make -C cart-slam_amd)"
+    for _ in range(5):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_config_errors_read_like_the_reference(tmp_path):
     tmp = str(tmp_path)
     src, _ = make_dataset(tmp, 1, 64, 32)
