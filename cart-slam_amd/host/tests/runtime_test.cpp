@@ -9,7 +9,10 @@
 #include <future>
 #include <thread>
 
+#include <cstring>
+
 #include "cartslam_amd/cartslam.hpp"
+#include "cartslam_amd/png.hpp"
 
 using namespace cart;
 
@@ -71,7 +74,20 @@ class ModuleC : public SyncWrapperSystemModule {
 };
 }  // namespace
 
-int main() {
+int main(int argc, char **argv) {
+    // runtime_test --png FILE: decode with the host's PNG reader and dump "w h channels\n" + the pixels (tests/test_host.py)
+    if (argc == 3 && !std::strcmp(argv[1], "--png")) {
+        try {
+            util::HostImage img;
+            if (!util::readPng(argv[2], img)) { std::printf("missing\n"); return 2; }
+            std::printf("%d %d %d\n", img.w, img.h, img.channels);
+            std::fwrite(img.data.data(), 1, img.data.size(), stdout);
+            return 0;
+        } catch (const std::exception &e) {
+            std::printf("error: %s\n", e.what());
+            return 3;
+        }
+    }
     // 1. the pool alone: tasks that block on tasks posted after them (a fixed-size pool would deadlock), reuse of threads
     {
         WorkerPool pool(4);

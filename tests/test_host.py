@@ -66,6 +66,67 @@ def test_runtime_without_gpu():
         assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def _write_png(path, img, color_type, filters):
+    """Own PNG writer (zlib only): img uint8 [h, w, c]; one filter type per row from `filters`, cycled (0 None, 1 Sub, 2 Up,
+    3 Average, 4 Paeth), so that every branch of the reader's un-filtering is exercised -- PIL picks filters adaptively."""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    raw, prev = bytearray(), np.zeros(w * c, np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        ft = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(c, np.int32), cur[:-c]])
+        upleft = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+        if ft == 0: f = cur
+        elif ft == 1: f = cur - left
+        elif ft == 2: f = cur - prev
+        elif ft == 3: f = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            f = cur - pred
+        raw.append(ft); raw += (f & 255).astype(np.uint8).tobytes()
+        prev = cur
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    comp = zlib.compress(bytes(raw), 6)
+    idat = b"".join(chunk(b"IDAT", comp[i:i + 1000]) for i in range(0, len(comp), 1000))   # several IDAT chunks
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0)) +
+                 chunk(b"tEXt", b"Comment\0ancillary chunks are skipped") + idat + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("color_type,channels", [(0, 1), (2, 3), (4, 2), (6, 4)])
+def test_png_reader(tmp_path, color_type, channels):
+    """The host's PNG reader (host/src/png.cpp; cv::imread of src/sources/kitti.cpp:131,152-153): gray / RGB / gray+alpha /
+    RGBA, every row filter, several IDAT chunks, odd sizes -> BGR bytes like cv::imread's default; malformed files throw."""
+    exe = os.path.join(os.path.dirname(EXE), "runtime_test")
+    rng = np.random.default_rng(color_type)
+    for (w, h), filters in (((37, 11), [0, 1, 2, 3, 4]), ((1, 1), [4]), ((64, 9), [3, 4, 1]), ((5, 40), [2, 4])):
+        img = rng.integers(0, 256, (h, w, channels)).astype(np.uint8)
+        img[:, : w // 2] //= 16   # smooth regions as well: small differences exercise the Paeth tie rules
+        path = str(tmp_path / f"t_{color_type}_{w}x{h}.png")
+        _write_png(path, img, color_type, filters)
+        r = subprocess.run([exe, "--png", path], capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stdout[:200]
+        head, _, body = r.stdout.partition(b"\n")
+        gw, gh, gc = (int(v) for v in head.split())
+        # cv::imread(path) = IMREAD_COLOR: always 3-channel BGR, gray replicated, alpha dropped
+        exp = np.repeat(img[..., :1], 3, axis=2) if channels <= 2 else img[..., 2::-1]
+        assert (gw, gh, gc) == (w, h, 3)
+        got = np.frombuffer(body, np.uint8).reshape(exp.shape)
+        assert (got == exp).all(), f"{w}x{h} filters {filters}"
+    # truncated data and a wrong signature fail loudly; a missing file is reported as such
+    data = open(path, "rb").read()
+    bad = str(tmp_path / "bad.png"); open(bad, "wb").write(data[: len(data) // 2])
+    assert subprocess.run([exe, "--png", bad], capture_output=True, timeout=60).returncode == 3
+    open(bad, "wb").write(b"JFIF" + data[4:])
+    assert subprocess.run([exe, "--png", bad], capture_output=True, timeout=60).returncode == 3
+    assert subprocess.run([exe, "--png", str(tmp_path / "none.png")], capture_output=True, timeout=60).returncode == 2
+
+
 def test_config_errors_read_like_the_reference(tmp_path):
     tmp = str(tmp_path)
     src, _ = make_dataset(tmp, 1, 64, 32)
