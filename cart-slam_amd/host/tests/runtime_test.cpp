@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "cartslam_amd/cartslam.hpp"
+#include "cartslam_amd/coalescer.hpp"
 #include "cartslam_amd/png.hpp"
 
 using namespace cart;
@@ -108,6 +109,47 @@ int main(int argc, char **argv) {
         bool threw = false;
         try { thrower.get(); } catch (const std::runtime_error &) { threw = true; }
         CHECK(threw);
+    }
+    // 1b. the frame coalescer: 24 threads x 40 requests of two incompatible kinds; every request runs exactly once, in a group of
+    //     its own kind of at most 6, never more than 2 groups at a time; a failing group fails each of its members and nobody else
+    {
+        struct Req : CoalescedRequest { int kind = 0, id = 0; int ran = 0; };
+        std::atomic<int> inFlight{0}, maxInFlight{0}, groups{0}, biggest{0};
+        std::atomic<bool> mixed{false}, oversized{false};
+        FrameCoalescer<Req> co(
+            6, 2, [](const Req &a, const Req &b) { return a.kind == b.kind; },
+            [&](const std::vector<Req *> &g) {
+                const int now = ++inFlight;
+                int seen = maxInFlight.load();
+                while (now > seen && !maxInFlight.compare_exchange_weak(seen, now)) {}
+                if ((int)g.size() > 6) oversized = true;
+                int big = biggest.load();
+                while ((int)g.size() > big && !biggest.compare_exchange_weak(big, (int)g.size())) {}
+                bool fail = false;
+                for (Req *q : g) { if (q->kind != g[0]->kind) mixed = true; ++q->ran; fail |= q->id == 13; }
+                ++groups;
+                std::this_thread::sleep_for(std::chrono::microseconds(300));   // "the GPU is busy": later requests gather meanwhile
+                --inFlight;
+                if (fail) throw std::runtime_error("group with request 13");
+            });
+        std::vector<std::thread> threads;
+        std::atomic<int> thrown{0}, completed{0}, ranTwice{0};
+        for (int t = 0; t < 24; ++t)
+            threads.emplace_back([&, t]() {
+                for (int k = 0; k < 40; ++k) {
+                    Req r; r.kind = t & 1; r.id = t * 40 + k;
+                    try { co.run(r); ++completed; } catch (const std::runtime_error &) { ++thrown; }
+                    if (r.ran != 1) ++ranTwice;
+                }
+            });
+        for (auto &t : threads) t.join();
+        CHECK(completed + thrown == 24 * 40);
+        CHECK(ranTwice == 0);
+        CHECK(!mixed && !oversized);
+        CHECK(maxInFlight <= 2);
+        CHECK(thrown >= 1 && thrown <= 6);          // request 13 and whoever shared its group
+        CHECK(biggest >= 2);                        // groups did form while two were "on the GPU"
+        CHECK(co.meanGroup() > 1.0 && groups < 24 * 40);
     }
     // 2. the System: consumers listed before their providers, 12 frames in flight, retention 32
     const int frames = 400;
