@@ -13,6 +13,7 @@
 
 #include "cartslam_amd/cartslam.hpp"
 #include "cartslam_amd/coalescer.hpp"
+#include "cartslam_amd/modules/superpixels.hpp"
 #include "cartslam_amd/png.hpp"
 
 using namespace cart;
@@ -150,6 +151,39 @@ int main(int argc, char **argv) {
         CHECK(thrown >= 1 && thrown <= 6);          // request 13 and whoever shared its group
         CHECK(biggest >= 2);                        // groups did form while two were "on the GPU"
         CHECK(co.meanGroup() > 1.0 && groups < 24 * 40);
+    }
+    // 1c. FrameOrder: 60 frames enter from 12 threads in scrambled order and take their turns in id order; every fifth frame
+    //     never takes its turn (its module "failed") and is only reported finished -- before or after its predecessors
+    {
+        FrameOrder order;
+        std::mutex m;
+        std::vector<uint32_t> sequence;
+        std::vector<std::thread> threads, turns;
+        // ids 1..60 dealt to 12 threads round-robin in reverse, so that late frames arrive first
+        for (int t = 0; t < 12; ++t)
+            threads.emplace_back([&, t]() {
+                for (int k = 4; k >= 0; --k) {
+                    const uint32_t id = (uint32_t)(1 + t + 12 * k);
+                    if (k != 4) std::this_thread::sleep_for(std::chrono::microseconds(50 * (12 - t)));
+                    if (id % 5 == 0) { order.finish(id); order.finish(id); continue; }   // idempotent
+                    // frames of one thread come in descending order: each would block the thread for its predecessors, which
+                    // live on other threads (and on this one!) -- so take the turn on a helper thread like the worker pool does
+                    std::thread turn([&order, &m, &sequence, id]() {
+                        FrameOrder::Turn turn(order, id);
+                        std::lock_guard<std::mutex> lock(m);
+                        sequence.push_back(id);
+                    });
+                    std::lock_guard<std::mutex> lock(m);
+                    turns.push_back(std::move(turn));
+                }
+            });
+        for (auto &t : threads) t.join();
+        for (auto &t : turns) t.join();
+        std::lock_guard<std::mutex> lock(m);
+        CHECK(sequence.size() == 48);
+        bool ascending = true;
+        for (size_t i = 1; i < sequence.size(); ++i) ascending &= sequence[i] > sequence[i - 1];
+        CHECK(ascending);
     }
     // 2. the System: consumers listed before their providers, 12 frames in flight, retention 32
     const int frames = 400;
