@@ -277,6 +277,9 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     g.npx = (size_t)g.w * g.h;
     g.census_elems = (size_t)g.h * g.cpitch;
     g.slab_bytes = g.npx * g.D;
+#ifdef CART_EXPERIMENTS   // address-mapping experiments: distance between the slabs of two paths
+    if (const char *pad = std::getenv("CART_SLAB_PAD")) g.slab_bytes += (std::strtoul(pad, nullptr, 0) + 255) & ~(size_t)255;
+#endif
     e->uniq = (float)(100 - params->uniqueness_ratio) / 100.0f;  // oracle S5
     const size_t n = (size_t)params->max_inflight;
     int rc = 0;
@@ -1355,7 +1358,7 @@ int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, si
         if (bytes < need) return fail("buffer too small");
         HIP_TRY(hipMemcpy2D(host_dst, (size_t)g.w * 4, c, (size_t)g.cpitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
     } else if (what >= CART_DBG_PATH0 && what < CART_DBG_PATH0 + g.P) {
-        src = e->slabs + ((size_t)slot * g.P + (what - CART_DBG_PATH0)) * g.slab_bytes; need = g.slab_bytes;
+        src = e->slabs + ((size_t)slot * g.P + (what - CART_DBG_PATH0)) * g.slab_bytes; need = g.npx * g.D;   // slab_bytes is the stride
         if (bytes < need) return fail("buffer too small");
         std::vector<uint8_t> raw(need);
         HIP_TRY(hipMemcpy(raw.data(), src, need, hipMemcpyDeviceToHost));
