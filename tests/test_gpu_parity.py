@@ -636,6 +636,29 @@ def test_launch_plans_agree_at_full_size(torch_cuda):
     assert (a[0] == O.disparity_module(ls[0], rs[0], D, P, 4, radius=2, iterations=1)).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,D,P,n", [(1242, 375, 64, 4, 16), (1242, 375, 256, 4, 16), (1920, 1080, 256, 8, 4)])
+def test_launch_plans_agree_at_the_other_baseline_sizes(torch_cuda, w, h, D, P, n):
+    """configs[1], the reference's default configuration and configs[3] at the bench's batch sizes: the plan AUTO picks, the
+    forced SLABS and the forced FUSED_UP give the same bits (16 frames per launch exercise the residency cap of the aggregation
+    launch and the u16 right-view rows of the sweep at full width); frame 0 equals the oracle where it finishes in seconds."""
+    torch = torch_cuda
+    ls, rs = synth.make_batch(2, w, h, D, 4, seed=77)
+    L = dev(torch, np.concatenate([ls] * (n // 2))); R = dev(torch, np.concatenate([rs] * (n // 2)))
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)
+    auto = eng.describe_plan(n)["plan"]
+    assert auto == ("fused_up" if D == 256 else "slabs")
+    a = eng.compute_disparity(L, R).cpu().numpy()
+    for plan in ("slabs", "fused_up"):
+        eng.set_plan(plan)
+        b = eng.compute_disparity(L, R).cpu().numpy()
+        assert (a == b).all(), plan
+    eng.close()
+    assert (a[0] == a[2]).all() and (a[0] != a[1]).any()
+    if w * h * D <= 1242 * 375 * 256:
+        assert (a[0] == O.disparity_module(ls[0], rs[0], D, P, 4, radius=2, iterations=1)).all()
+
+
 def test_tile_loaders_on_the_reference_ramp(torch_cuda):
     """The only "test vector" in the reference tree is the 1280x720 coordinate ramp v = y*1280 + x that its debug kernel
     feeds to copyToShared (src/utils/sanity_check.cu:57-65): every element identifies its own position, so a
