@@ -43,32 +43,46 @@ def alg_bytes_wta(w, h, D, P):
 
 CPU_BASELINE_CHILD = r"""
 import json, os, sys, time
-root, w, h, D, P, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+root, w, h, D, P, budget, verify_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6]), sys.argv[7]
+verify = json.loads(sys.argv[8])   # {"frame number of synth.make_pair": [the 6 plane parameters the GPU run classified it with]}
 sys.path[:0] = [os.path.join(root, "cart-slam_amd"), os.path.join(root, "tests")]
 import numpy as np
 import oracle_lib as O      # cpu_baseline leg: allowed importer of oracle/
 from cartslam import synth
 O.build()
-l, r, _ = synth.make_pair(w, h, D, 4)
-def one():
+def one(l, r):
     d = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
     dd, hist = O.plane_derivative(d)
     ok, pp = O.histogram_peak_params(hist)
     pl = O.classify(dd, pp)
     O.ccl(pl)
-one(); one()      # warm-up: page faults, thread pool
+    return d, dd
+# The frames whose GPU outputs bench.py checks after its timed region (also the warm-up: page faults, thread pool): the
+# oracle's disparity, and its plane labels under the parameters the GPU run used for that frame (the parameter schedule
+# depends on every frame the run has seen; it has its own tests).
+keep = {}
+for f, params in verify.items():
+    l, r, _ = synth.make_pair(w, h, D, 4, frame=int(f))
+    d, dd = one(l, r)
+    keep["disp_" + f], keep["planes_" + f] = d, O.classify(dd, tuple(params))
+if verify_path:
+    np.savez(verify_path, **keep)
+l, r, _ = synth.make_pair(w, h, D, 4)
+one(l, r); one(l, r)
 times, t_all = [], time.perf_counter()
 while len(times) < 3 or (time.perf_counter() - t_all < budget and len(times) < 40):
-    t0 = time.perf_counter(); one(); times.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); one(l, r); times.append(time.perf_counter() - t0)
 times.sort()
 print(json.dumps({"median_s": times[len(times) // 2], "min_s": times[0], "max_s": times[-1], "reps": len(times)}))
 """
 
 
-def cpu_baseline(w, h, D, P, seconds_budget=12.0):
+def cpu_baseline(w, h, D, P, seconds_budget=12.0, verify_path="", verify=None):
     """Times the CPU oracle (the 'port': oracle/cart_oracle.c, OpenMP) on this box's host cores: a child process with no
     torch / GPU in it, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: both have to be set before libgomp
-    loads), median over >= 3 whole-pair repetitions, spread reported."""
+    loads), median over >= 3 whole-pair repetitions, spread reported.  The same child writes the oracle's disparity and
+    plane labels of the frames in `verify` ({frame number of synth.make_pair: plane parameters}) to `verify_path` for
+    the bench's self-check."""
     import math
     import subprocess
     visible = os.cpu_count() or 1
@@ -95,7 +109,8 @@ def cpu_baseline(w, h, D, P, seconds_budget=12.0):
         env["OMP_PLACES"] = "cores"
     else:
         env.pop("OMP_PLACES", None)
-    r = subprocess.run([sys.executable, "-c", CPU_BASELINE_CHILD, ROOT, str(w), str(h), str(D), str(P), str(seconds_budget)],
+    r = subprocess.run([sys.executable, "-c", CPU_BASELINE_CHILD, ROOT, str(w), str(h), str(D), str(P), str(seconds_budget), verify_path,
+                        json.dumps({str(k): [int(x) for x in v] for k, v in (verify or {}).items()})],
                        env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline child failed: " + r.stderr[-2000:])
@@ -110,8 +125,8 @@ def cpu_baseline(w, h, D, P, seconds_budget=12.0):
 
 def launch_ranks(args):
     """Plain `python bench.py --gpus N` (no RANK in the environment): start N fresh rank processes through
-    torch.distributed.run and relay their output.  Nothing in this process has initialised a GPU
-    (torch.cuda.device_count() does not), so the children start from a clean state."""
+    torch.distributed.run and relay their output.  This process only counts the devices (on ROCm that opens the HIP
+    runtime here, which is harmless: the ranks are fresh child processes, nothing is exec'ed over this one)."""
     import socket
     import subprocess
     import torch
@@ -144,8 +159,8 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (the default)")
-    ap.add_argument("--split", action="store_true", help="census of batch i+1 on a third stream, post-WTA stages on the side stream (StereoPipeline split_stages; measured slower except at D=64 / 4 paths)")
-    ap.add_argument("--deferred", action="store_true", help="two streams, the plane stages of batch i gated behind the aggregation of batch i+1 (StereoPipeline overlap=\"deferred\")")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps steps is run this many times; `value` is the median block, `spread` the fastest / slowest")
+    ap.add_argument("--collective-timeout", type=float, default=120.0, help="seconds after which a torch.distributed call gives up (a dead peer then ends the job non-zero instead of hanging it)")
     ap.add_argument("--sequence", action="store_true", help="also time the batched-sequence mode (BASELINE configs[4]): frames start on rank 0, "
                     "are scattered frame k -> rank k mod N, outputs are gathered back on rank 0; informational, never `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -159,11 +174,10 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
-    import numpy as np
+    import datetime
     import torch
     import torch.distributed as dist
-    from cartslam import Engine, synth
-    from cartslam.pipeline import StereoPipeline
+    from cartslam.pipeline import CollectiveError
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,12 +192,34 @@ def main():
                  "--allow-shared-gpu is for rehearsals only")
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if world > 1 or args.sequence:   # the sequence leg runs its scatter / gather through the backend even with one rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        # a collective that a peer never joins fails after this long (RCCL: the watchdog thread aborts the process and logs
+        # the rank and the operation; gloo: the call raises) -- either way the job ends non-zero instead of hanging
+        timeout = datetime.timedelta(seconds=args.collective_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index), timeout=timeout)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=timeout)
+    try:
+        run(args, world, rank, dev_index)
+    except CollectiveError as e:
+        sys.stderr.write(f"bench.py: {e}\n")
+        sys.stderr.flush()
+        os._exit(3)   # not sys.exit: destroy_process_group / atexit handlers would wait for the peer that is gone
+
+
+def run(args, world, rank, dev_index):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cartslam import Engine, synth
+    from cartslam.pipeline import StereoPipeline
 
     w, h, D, P, B = args.width, args.height, args.disparities, args.paths, args.batch
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1,
@@ -193,15 +229,12 @@ def main():
     if args.chunk:
         eng.set_chunk_frames(args.chunk)
     plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
-    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True,
-                          overlap=False if args.no_overlap else "deferred" if args.deferred else True if args.overlap else "auto",
-                          split_stages=args.split)
-    # this rank's frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
-    n_distinct = min(B, 4)
-    ls, rs = synth.make_batch(n_distinct, w, h, D, 4, first_frame=rank * n_distinct)
-    reps = (B + n_distinct - 1) // n_distinct
-    left = torch.from_numpy(np.concatenate([ls] * reps)[:B]).cuda()
-    right = torch.from_numpy(np.concatenate([rs] * reps)[:B]).cuda()
+    pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=False if args.no_overlap else "auto")
+    # this rank's B distinct frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
+    first_frame = rank * B
+    ls, rs = synth.make_batch(B, w, h, D, 4, first_frame=first_frame)
+    left = torch.from_numpy(ls).cuda()
+    right = torch.from_numpy(rs).cuda()
 
     torch.cuda.synchronize()
     resident = torch.cuda.current_stream().record_event()   # the inputs are complete from here on (they live in HBM for the whole run)
@@ -212,22 +245,37 @@ def main():
 
     # Untimed pre-warm, before the W warm-up steps the contract asks for: first touch of the workspaces (15 GB of slabs), code
     # object loads, allocator pools and the clock ramp of a GPU that has just been handed over idle.
-    for _ in range(32):   # ~0.1 s of GPU work at the headline configuration
+    PREWARM = 32          # ~0.1 s of GPU work at the headline configuration; reported as "prewarm_steps"
+    for _ in range(PREWARM):
         pipe.process_batch(left, right, inputs_ready=resident)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         pipe.process_batch(left, right, inputs_ready=resident)
     torch.cuda.synchronize()
     eng.set_timing(True)  # hipEvents around each stage, on the stream the kernels are launched on
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.process_batch(left, right, inputs_ready=resident)
-    pipe.flush()   # deferred mode: the plane stages of the last batch belong to the timed region (no-op otherwise)
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed block -- EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks -- is run
+    # --repeats times; `value` is the median block (a 20-step block is 60 ms: single blocks differ by a few per cent)
+    blocks, last = [], None
+    for _ in range(max(1, args.repeats)):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = pipe.process_batch(left, right, inputs_ready=resident)
+        torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        blocks.append(dt)
+    elapsed = sorted(blocks)[len(blocks) // 2]
     stages, ncalls = eng.collect_timing()
     eng.set_timing(False)
+    # what the LAST timed step produced for the first and the last frame of this rank's batch (checked against the oracle
+    # below, outside every timed region)
+    check_frames = sorted({0, B - 1})
+    got = {k: {"disp": last["disparity"][k].cpu().numpy(), "planes": last["planes"][k].cpu().numpy(),
+               "params": [int(v) for v in last["params"][k].cpu().numpy()]} for k in check_frames} if rank == 0 else {}
     copy_gbps = None
     if rank == 0:
         # achievable-copy ceiling of THIS box ("quote both fractions"): device-to-device copy of 2 GiB,
@@ -270,13 +318,10 @@ def main():
                 upload(i)
             upload(i + 1)
             ev = uploaded.pop(i)
-            torch.cuda.current_stream().wait_event(ev) if pipe.pre is None else None   # otherwise the census stream waits for the upload
-            o = pipe.process_batch(dl, dr, inputs_ready=ev)
+            o = pipe.process_batch(dl, dr, inputs_ready=ev)   # the main stream waits for the upload
             consumed[i % 3] = torch.cuda.current_stream().record_event()
             download(o)
         def download(o):
-            if o is None:   # deferred mode: the outputs come one call later (the last ones from flush())
-                return
             d2h.wait_event(o["done"]) if "done" in o else d2h.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(d2h):
                 if method[0] == "narrow":   # a few workgroups write straight into the pinned (device-mapped) host buffers
@@ -295,7 +340,6 @@ def main():
             tp = time.perf_counter()
             for _ in range(n_pcie):
                 pcie_step(step_no); step_no += 1
-            download(pipe.flush())
             torch.cuda.synchronize()
             tried[m] = round(B * n_pcie / (time.perf_counter() - tp), 1)
         best = max(tried, key=tried.get)
@@ -304,32 +348,48 @@ def main():
                 "download": names[best], "pairs_per_s_by_download": tried}
     seq = None
     if args.sequence:
-        # Informational (never `value`): BASELINE configs[4].  64 frames when they divide over the ranks and fit a batch.
-        n_seq = 64 if (64 % world == 0 and 64 // world <= B) else world * B
+        # Informational (never `value`): BASELINE configs[4], a sequence that starts on rank 0.  64 frames when they fit the
+        # ranks' batches, else one batch per rank.  Timed twice: one sequence at a time (scatter -> kernels -> gather, wait),
+        # and pipelined (StereoPipeline.submit_sequence: the scatter of sequence i+1 and the gather of sequence i-1 on the copy
+        # stream beside the kernels of sequence i).
+        n_seq = 64 if -(-64 // world) <= B else world * B
+        seq_pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=False if args.no_overlap else "auto",
+                                  always_exchange=True)
         sl = sr = None
         if rank == 0:
-            k = (n_seq + n_distinct - 1) // n_distinct
+            k = -(-n_seq // B)
             sl = torch.from_numpy(np.concatenate([ls] * k)[:n_seq]).cuda()
             sr = torch.from_numpy(np.concatenate([rs] * k)[:n_seq]).cuda()
+        n_rounds = 8
+        def timed(fn):
+            torch.cuda.synchronize(); barrier()
+            ts = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(); barrier()
+            t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        def serial():
+            for _ in range(n_rounds):
+                seq_got[0] = seq_pipe.process_sequence(sl, sr, n_seq)
+                torch.cuda.synchronize()
+        def pipelined():
+            hs = [seq_pipe.submit_sequence(sl, sr, n_seq) for _ in range(n_rounds)]
+            for hnd in hs:
+                seq_got[0] = hnd.result()
+        seq_got = [None]
         for _ in range(2):
-            pipe.process_sequence(sl, sr, n_seq)
-        torch.cuda.synchronize(); barrier()
-        ts = time.perf_counter()
-        n_rounds = 5
-        for _ in range(n_rounds):
-            got = pipe.process_sequence(sl, sr, n_seq)
-        torch.cuda.synchronize(); barrier()
-        tseq = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(tseq, op=dist.ReduceOp.MAX)
+            seq_pipe.process_sequence(sl, sr, n_seq)
+        t_serial = timed(serial)
+        t_pipe = timed(pipelined)
         if rank == 0:
-            assert tuple(got["disparity"].shape) == (n_seq, h, w) and tuple(got["planes"].shape) == (n_seq, h, w)
-            seq = {"frames": n_seq, "pairs_per_s": round(n_seq * n_rounds / float(tseq.item()), 1), "rounds": n_rounds,
-                   "moved": "scatter of 2 gray images per frame from rank 0, gather of s16 disparity + u8 planes to rank 0"}
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            assert tuple(seq_got[0]["disparity"].shape) == (n_seq, h, w) and tuple(seq_got[0]["planes"].shape) == (n_seq, h, w)
+            seq = {"frames": n_seq, "rounds": n_rounds,
+                   "pairs_per_s": round(n_seq * n_rounds / t_pipe, 1),
+                   "pairs_per_s_one_sequence_at_a_time": round(n_seq * n_rounds / t_serial, 1),
+                   "moved": "scatter of 2 gray images per frame from rank 0, gather of s16 disparity + u8 planes to rank 0",
+                   "pipelining": "scatter of sequence i+1 and gather of sequence i-1 on a copy stream beside the kernels of sequence i"}
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -351,6 +411,7 @@ def main():
             # dominant kernel = the aggregation launch: census re-read + slab write of all P paths
             roof_kernel = "aggregate_kernel (all paths of all frames in one launch)"
             agg_bytes, roof_ms = alg_bytes_aggregate(w, h, D, P) * fpl, agg_ms
+            moved_bytes = agg_bytes
             traffic = measured_traffic("aggregate")
         else:
             # Fused plans move fewer bytes than SURVEY 8d's table assumes (some slabs never exist).  The line is still
@@ -358,14 +419,19 @@ def main():
             # launches that together do that work (aggregation + WTA sweep); `traffic` is what they really moved.
             roof_kernel = f"aggregation launch(es) + WTA sweep, plan {plan['plan']} ({plan['slabs_written']} of {P} slabs materialised)"
             agg_bytes, roof_ms = (alg_bytes_aggregate(w, h, D, P) + alg_bytes_wta(w, h, D, P)) * fpl, agg_ms + wta_ms
+            # what this plan has to move: census re-read per path, the materialised slabs written once and read once, WTA maps
+            moved_bytes = w * h * (8 * P + 2 * plan["slabs_written"] * D + 4) * fpl
             ta, tw = measured_traffic("aggregate"), measured_traffic("wta")
             traffic = ta + tw if ta and tw else None
         achieved = agg_bytes / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
+        moved_gbps = moved_bytes / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
         device_ms_per_pair = sum(stages.values()) / fpl if stages else None
         out = {
             "metric": "stereo-pairs/sec @1242x375xD=128; achieved HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "stereo-pairs/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "prewarm_steps": PREWARM, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "repeats": len(blocks), "spread": {"min": round(pairs / max(blocks), 2), "max": round(pairs / min(blocks), 2),
+                                               "note": f"value = median of {len(blocks)} timed blocks of {args.steps} steps each"},
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{w}x{h} gray stereo, D={D}, {P}-direction SGM + interpolate(r=2,it=1) + plane "
                                    f"labelling (histogram_peak) + CCL; " +
@@ -373,17 +439,21 @@ def main():
                                     (1242, 375, 64, 4): "BASELINE.json configs[1]",
                                     (1920, 1080, 256, 8): "BASELINE.json configs[3]"}.get((w, h, D, P), "not a BASELINE.json configuration"),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B, "sharding": f"frames x{world}",
-                       "launch_plan": plan, "two_stream_pipelining": ("deferred" if pipe.deferred else True) if pipe.side is not None else False,
-                       "census_and_post_stages_off_the_main_stream": pipe.split_stages,
+                       "launch_plan": plan, "two_stream_pipelining": pipe.side is not None, "distinct_frames_per_batch": B,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": roof_kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (stored rocprofv3 PMC passes of this configuration: 2 x FETCH_SIZE + WRITE_SIZE), not a counter of this run" if traffic else None,
+                         "frac_basis": "SURVEY 8d table bytes: all P slabs written and read once",
                          "alg_bytes_per_launch": agg_bytes, "frames_per_launch": fpl, "launch_ms": round(roof_ms, 4),
                          "launches_timed": ncalls,
+                         # bytes the launch plan really has to move (equal to the table's for plan slabs); the copy-ceiling
+                         # fraction is priced with these, so a plan that skips slabs cannot print more than 1
+                         "moved_bytes_per_launch": moved_bytes, "frac_moved": round(moved_gbps / HBM_PEAK_GBS, 4),
                          "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
-                         "frac_of_copy_ceiling": round(achieved / copy_gbps, 4) if copy_gbps else None},
+                         "frac_of_copy_ceiling": round(moved_gbps / copy_gbps, 4) if copy_gbps else None},
             "stages_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
@@ -393,16 +463,40 @@ def main():
             wta_bytes = alg_bytes_wta(w, h, D, P) * fpl
             out["roofline_wta"] = {"bound": "hbm", "kernel": "wta_kernel", "achieved": round(wta_bytes / (wta_ms * 1e-3) / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wta_bytes / (wta_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "traffic": measured_traffic("wta"), "alg_bytes_per_launch": wta_bytes, "launch_ms": round(wta_ms, 4)}
+                                   "traffic": measured_traffic("wta"), "traffic_source": "profiles/traffic.json" if measured_traffic("wta") else None,
+                                   "alg_bytes_per_launch": wta_bytes, "launch_ms": round(wta_ms, 4)}
         if pcie:
             out["pcie_inclusive"] = pcie
             out["value_pcie_inclusive"] = pcie["pairs_per_s"]   # the same step with the pair uploaded and disparity + planes downloaded
         if seq:
             out["sequence_mode"] = seq
+        verified = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, h, D, P)
+            # the CPU leg: the oracle timed on the host cores; the same child also hands back the oracle's outputs of the first
+            # and the last frame of the batch, against which the LAST TIMED STEP's outputs are compared (outside every timed region)
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                vp = os.path.join(td, "verify.npz")
+                out["cpu_baseline"] = cpu_baseline(w, h, D, P, verify_path=vp, verify={first_frame + k: got[k]["params"] for k in check_frames})
+                z = np.load(vp)
+                bad = []
+                for k in check_frames:
+                    f = str(first_frame + k)
+                    if not (got[k]["disp"] == z["disp_" + f]).all():
+                        bad.append(f"disparity of frame {k}: {int((got[k]['disp'] != z['disp_' + f]).sum())} pixels differ")
+                    if not (got[k]["planes"] == z["planes_" + f]).all():
+                        bad.append(f"planes of frame {k}: {int((got[k]['planes'] != z['planes_' + f]).sum())} pixels differ")
+                verified = not bad
+                out["verification"] = {"frames": check_frames, "of": "the last timed step", "against": "oracle (cpu_baseline child): disparity bit-exact, "
+                                       "plane labels bit-exact under the parameters the run used", "mismatches": bad}
+        out["verified"] = verified   # None: not checked (multi-rank runs and --no-cpu-baseline have no CPU leg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        if verified is False:
+            sys.stderr.write("bench.py: the timed configuration's outputs differ from the oracle: " + "; ".join(bad) + "\n")
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            sys.exit(4)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

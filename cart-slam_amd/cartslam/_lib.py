@@ -56,8 +56,6 @@ PROTOTYPES = {
     "cart_engine_device_status": (_i, [_vp, C.POINTER(C.c_uint)]),
     "cart_compute_disparity": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
     "cart_compute_disparity_batch": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp]),
-    "cart_compute_disparity_batch_gated": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp, _vp]),
-    "cart_compute_disparity_batch_streams": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "cart_compute_disparity_multi": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
     "cart_interpolate": (_i, [_vp, _i, _vp, _sz, _sz, _i, _i, _i, _i, _vp]),
     "cart_disparity_derivative": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),

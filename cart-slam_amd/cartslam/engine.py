@@ -107,17 +107,14 @@ class Engine:
         return dst
 
     def device_status(self):
-        """Synchronises; 0 = healthy (bit 0: a pair sweep timed out waiting for its neighbour block)."""
+        """Synchronises, reads and clears the status word; 0 = healthy (bit 0: a pair sweep of plan "pairs" timed out
+        waiting for its neighbour block since the last query -- ask after synchronising when that plan is forced)."""
         st = C.c_uint(0)
         self._check(self._lib.cart_engine_device_status(self._h, C.byref(st)), "cart_engine_device_status")
         return st.value
 
     # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
-    def compute_disparity(self, left, right, out=None, gated_stream=None, census_stream=None, tail_stream=None):
-        """gated_stream (a torch.cuda.Stream): made to wait until this call's path aggregation has finished
-        (cart_compute_disparity_batch_gated); what the caller enqueues there afterwards runs beside the WTA, not the aggregation.
-        census_stream / tail_stream (cart_compute_disparity_batch_streams): the census runs on census_stream -- the inputs must
-        be complete THERE -- and the stages after the WTA on tail_stream, where the result is then produced."""
+    def compute_disparity(self, left, right, out=None):
         import torch
         ch = 3 if (left.dim() >= 3 and left.shape[-1] == 3 and left.shape[-2] == self.width
                    and left.shape[-3] == self.height) else 1
@@ -133,16 +130,6 @@ class Engine:
         if out is None:
             out = torch.empty(shape, dtype=torch.int16, device=left.device)
         _, op, os_, ofs = _geom(out, 1)
-        if census_stream is not None or tail_stream is not None:
-            sp = lambda st: C.c_void_p(st.cuda_stream) if st is not None else None
-            self._check(self._lib.cart_compute_disparity_batch_streams(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs, _stream_ptr(),
-                                                                       sp(census_stream), sp(tail_stream), sp(gated_stream)),
-                        "cart_compute_disparity_batch_streams")
-            return out
-        if gated_stream is not None:
-            self._check(self._lib.cart_compute_disparity_batch_gated(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs, _stream_ptr(),
-                                                                     C.c_void_p(gated_stream.cuda_stream)), "cart_compute_disparity_batch_gated")
-            return out
         self._check(self._lib.cart_compute_disparity_batch(self._h, n, lp, ls, lfs, rp, rs, rfs, ch, op, os_, ofs,
                                                            _stream_ptr()), "cart_compute_disparity_batch")
         return out

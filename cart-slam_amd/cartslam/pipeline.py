@@ -11,11 +11,41 @@ exactly what the reference's module would give when fed the same frames one by o
 Sharding: frames are independent up to the plane-parameter refresh.  The
 histogram the reference keeps is cumulative over frames and is consulted when id % update_interval
 == 1 (planeseg.cu:381-395), so the only exchange step is an all-gather of the per-frame 256-bin
-histograms (1 KB per frame); every rank then replays the schedule redundantly on the host.
+histograms (1 KB per frame); every rank then replays the schedule redundantly.
+
+Batched-sequence mode (BASELINE.json configs[4]): a sequence that lives on one rank is dealt out frame k -> rank k mod
+world with grouped point-to-point transfers (rank 0 has a direct xGMI link to every peer: no ring), every rank runs its
+share as one batch, and the outputs travel back the same way.  Sequences are double-buffered: the transfers run on a copy
+stream of their own, the scatter of sequence i+1 and the gather of sequence i-1 beside the kernels of sequence i
+(SequencePipeliner).
 """
 import numpy as np
 
 from .engine import PlaneParams, find_plane_params
+
+
+class CollectiveError(RuntimeError):
+    """A torch.distributed call of the sharded path failed or timed out; names the rank and the call so that a launcher's
+    log says which peer to look at (bench.py exits non-zero on it)."""
+
+    def __init__(self, rank, what, cause):
+        super().__init__(f"rank {rank}: collective '{what}' failed: {type(cause).__name__}: {cause}")
+        self.rank, self.what, self.cause = rank, what, cause
+
+
+def _guarded(what, group, fn):
+    """Runs one communication step; any failure (a dead peer's timeout, a backend error) becomes a CollectiveError."""
+    import torch.distributed as dist
+    try:
+        return fn()
+    except CollectiveError:
+        raise
+    except Exception as e:   # noqa: BLE001 -- every backend raises its own types
+        try:
+            rank = dist.get_rank(group)
+        except Exception:   # noqa: BLE001
+            rank = -1
+        raise CollectiveError(rank, what, e) from e
 
 
 class PlaneParameterSchedule:
@@ -55,45 +85,187 @@ def shard_ids(first_id, n_local, rank, world):
     return [first_id + k * world + rank for k in range(n_local)]
 
 
+def share_of(n_total, rank, world):
+    """Frames of an n_total-frame sequence that land on `rank` (frame k -> rank k mod world): the first n_total % world
+    ranks hold one frame more than the others."""
+    return len(range(rank, n_total, world))
+
+
+def _global_rank(group, r):
+    import torch.distributed as dist
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def _padded(t, n):
+    """t with zero frames appended up to n frames (the collectives move equal shares; short shares travel padded)."""
+    import torch
+    if t.shape[0] == n:
+        return t.contiguous()
+    return torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))])
+
+
 def scatter_sequence(frames, n_total, like, root=0, group=None):
-    """Batched-sequence mode (BASELINE.json configs[4]: a 64-frame sequence that starts on one rank): frame k of the
-    sequence goes to rank k mod world, the interleaving of shard_ids.  `frames` is the [n_total, ...] tensor on `root`
-    (ignored elsewhere); `like` = (per-frame shape, dtype, device) so that the other ranks can post their receive.
-    Returns this rank's [n_total / world, ...] tensor.  One scatter (RCCL: grouped point-to-point over xGMI, rank 0 has
-    a direct link to every peer) -- not a ring collective."""
+    """Batched-sequence mode (BASELINE.json configs[4]: a sequence that starts on one rank): frame k of the sequence goes
+    to rank k mod world, the interleaving of shard_ids; when n_total is not a multiple of the world size the first ranks
+    get one frame more (share_of; the short shares travel padded with one zero frame, which is dropped on arrival).
+    `frames` is the [n_total, ...] tensor on `root` (ignored elsewhere); `like` = (per-frame shape, dtype, device) so that
+    the other ranks can post their receive.  Returns this rank's [share_of(n_total, rank, world), ...] tensor.  One scatter
+    (RCCL: grouped ncclSend / ncclRecv over xGMI, rank 0 has a direct link to every peer) -- not a ring collective."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if n_total % world:
-        raise ValueError(f"sequence length {n_total} is not a multiple of the world size {world}")
+    if n_total < 1:
+        raise ValueError(f"sequence length {n_total} must be positive")
     shape, dtype, device = like
     on_host = dist.get_backend(group) == "gloo"   # RCCL moves device tensors; gloo (CPU rehearsals) moves host copies
-    mine = torch.empty((n_total // world,) + tuple(shape), dtype=dtype, device="cpu" if on_host else device)
+    wire_dev = "cpu" if on_host else device
+    n_max = -(-n_total // world)
+    mine = torch.empty((n_max,) + tuple(shape), dtype=dtype, device=wire_dev)
     parts = None
     if rank == root:
         if tuple(frames.shape) != (n_total,) + tuple(shape) or frames.dtype != dtype:
             raise ValueError(f"root holds {tuple(frames.shape)} {frames.dtype}, expected {(n_total,) + tuple(shape)} {dtype}")
-        parts = [(frames[r::world].cpu() if on_host else frames[r::world]).contiguous() for r in range(world)]
-    dist.scatter(mine, parts, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
-    return mine.to(device)
+        parts = [_padded(frames[r::world].to(wire_dev), n_max) for r in range(world)]
+    _guarded("scatter(sequence)", group, lambda: dist.scatter(mine, parts, src=_global_rank(group, root), group=group))
+    return mine[:share_of(n_total, rank, world)].to(device)
 
 
-def gather_sequence(local, root=0, group=None):
-    """Inverse of scatter_sequence: on `root` the frames of all ranks back in sequence order ([n_total, ...]), None elsewhere."""
+def gather_sequence(local, n_total=None, root=0, group=None):
+    """Inverse of scatter_sequence: on `root` the frames of all ranks back in sequence order ([n_total, ...]), None
+    elsewhere.  n_total defaults to world * local.shape[0] (equal shares)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if n_total is None:
+        n_total = world * local.shape[0]
+    if local.shape[0] != share_of(n_total, rank, world):
+        raise ValueError(f"rank {rank} holds {local.shape[0]} frames of a {n_total}-frame sequence, expected {share_of(n_total, rank, world)}")
     device = local.device
-    local = (local.cpu() if dist.get_backend(group) == "gloo" else local).contiguous()
+    n_max = -(-n_total // world)
+    local = _padded(local.cpu() if dist.get_backend(group) == "gloo" else local, n_max)
     wire = local.view(torch.uint8)   # images travel as bytes: neither RCCL nor gloo has a 16-bit integer type
     parts = [torch.empty_like(wire) for _ in range(world)] if rank == root else None
-    dist.gather(wire, parts, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+    _guarded("gather(sequence)", group, lambda: dist.gather(wire, parts, dst=_global_rank(group, root), group=group))
     if rank != root:
         return None
-    full = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
+    full = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=device)
     for r in range(world):
-        full[r::world] = parts[r].view(local.dtype).to(device)
+        n_r = share_of(n_total, r, world)
+        if n_r:
+            full[r::world] = parts[r].view(local.dtype)[:n_r].to(device)
     return full
+
+
+class SequenceHandle:
+    """Result of SequencePipeliner.submit(): result() returns the gathered outputs ({key: [n_total, ...] tensor} on the
+    root rank, {key: None} elsewhere).  Collectives are posted in program order, so every rank must call submit() /
+    result() at the same points of its program."""
+
+    def __init__(self, owner, n_total, root, keys):
+        self._owner, self.n_total, self.root, self.keys = owner, n_total, root, keys
+        self.local = None        # {key: this rank's share}, set when the compute has been enqueued
+        self.computed = None     # event: the share's outputs are complete (device backends)
+        self.gathered = None     # event: the gathered outputs are complete
+        self.value = None
+
+    def result(self, block=True):
+        """block=True: returns when the outputs are in place (host-synchronous, like a future).  block=False: makes the
+        CURRENT stream wait for them instead and returns at once."""
+        self._owner._finish(self, block)
+        return self.value
+
+
+class SequencePipeliner:
+    """Double-buffered batched-sequence mode over any per-rank compute function.
+
+    submit(i+1) posts the scatter of sequence i+1, THEN the gather of sequence i (whose kernels are still running), then
+    enqueues the kernels of i+1: on the copy stream the scatter of i+1 is not queued behind the wait for sequence i's
+    kernels, so it runs beside them, and the gather of i runs beside the kernels of i+1.  `compute(left, right, n_total)`
+    -> dict of tensors with a leading frame dimension (+ optionally "done": an event after which they are complete).
+    On the gloo backend (CPU rehearsals) every transfer blocks the host, so the pipeline degenerates to the serial order
+    -- with the same results, which is what the rehearsal checks."""
+
+    def __init__(self, compute, per_frame_shape, group=None, device="cpu"):
+        import torch
+        self.compute, self.shape, self.group = compute, tuple(per_frame_shape), group
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.xfer = torch.cuda.Stream(self.device) if self.cuda else None
+        self._pending = None     # handle whose kernels are enqueued and whose gather has not been posted yet
+
+    def _on_xfer(self):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.xfer) if self.cuda else contextlib.nullcontext()
+
+    def submit(self, left, right, n_total, root=0, keys=("disparity", "planes")):
+        import torch
+        h = SequenceHandle(self, n_total, root, tuple(keys))
+        like = (self.shape, torch.uint8, self.device)
+        main = torch.cuda.current_stream(self.device) if self.cuda else None
+        if self.cuda:
+            self.xfer.wait_stream(main)   # the caller wrote left / right on its stream
+            for t in (left, right):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.xfer)
+        with self._on_xfer():
+            l = scatter_sequence(left, n_total, like, root, self.group)
+            r = scatter_sequence(right, n_total, like, root, self.group)
+            scattered = self.xfer.record_event() if self.cuda else None
+        prev, self._pending = self._pending, None
+        if prev is not None:
+            self._post_gather(prev)
+        if self.cuda:
+            main.wait_event(scattered)
+            for t in (l, r):
+                t.record_stream(main)
+        out = self.compute(l, r, n_total)
+        missing = [k for k in keys if k not in out]
+        if missing:
+            raise KeyError(f"the compute function produced no {missing}")
+        h.local = {k: out[k] for k in keys}
+        if self.cuda:
+            h.computed = out["done"] if "done" in out else main.record_event()
+        self._pending = h
+        return h
+
+    def _post_gather(self, h):
+        import torch
+        with self._on_xfer():
+            if self.cuda:
+                self.xfer.wait_event(h.computed)
+            h.value = {}
+            for k in h.keys:
+                t = h.local[k]
+                if not torch.is_tensor(t):
+                    raise TypeError(f"output '{k}' is not a tensor and cannot be gathered")
+                if self.cuda:
+                    t.record_stream(self.xfer)
+                h.value[k] = gather_sequence(t, h.n_total, h.root, self.group)
+            h.gathered = self.xfer.record_event() if self.cuda else None
+        h.local = None
+
+    def _finish(self, h, block):
+        import torch
+        if h is self._pending:
+            self._pending = None
+            self._post_gather(h)
+        if h.value is None:
+            raise RuntimeError("this sequence's gather was never posted (handle of another pipeliner?)")
+        if self.cuda and h.gathered is not None:
+            if block:
+                h.gathered.synchronize()
+            else:
+                torch.cuda.current_stream(self.device).wait_event(h.gathered)
+            for v in h.value.values():
+                if v is not None:
+                    v.record_stream(torch.cuda.current_stream(self.device))
+
+    def drain(self):
+        """Posts the gather of the sequence that is still pending (e.g. before the process group is destroyed)."""
+        if self._pending is not None:
+            h, self._pending = self._pending, None
+            self._post_gather(h)
 
 
 class StereoPipeline:
@@ -103,7 +275,7 @@ class StereoPipeline:
 
     def __init__(self, engine, provider="histogram_peak", static_params=None, update_interval=30, reset_interval=10,
                  with_ccl=True, group=None, device_schedule=True, overlap=False, max_components=4096, keep_hists=False,
-                 always_exchange=False, split_stages=False):
+                 always_exchange=False):
         import torch
         from .engine import DevicePlaneSchedule
         self.engine = engine
@@ -123,167 +295,135 @@ class StereoPipeline:
             self.rank = torch.distributed.get_rank(group)
         self.next_id = 1
         self._hist = None
-        # overlap=True: the plane stages of batch i run on a side stream while the main stream already computes the
-        # disparity of batch i+1 (the plane stages are short, latency-bound launches that leave the GPU mostly idle).
-        # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id
-        # order.  The outputs are then produced on `self.side` ("disparity" too when split_stages is on): synchronise (or
-        # wait for out["done"]) before reading them on another stream.  Needs engine max_inflight >= 2 * batch.
-        # overlap="auto" = on.  Measured (profiles/tools/r02_deferred.sh, 16 pairs per step, ms per step one stream / side stream /
-        # deferred, after the residency cap of the aggregation launch): D=128 P=8 3.20 / 3.02 / 3.10, D=256 P=4 3.07 / 2.98 /
-        # 3.08, D=128 P=4 1.80 / 1.74 / 1.76, 1920x1080 D=256 P=8 (4 pairs) 6.13 / 5.99 / 6.00, D=64 P=4 1.28 / 1.24 / 1.20.
-        # (Before that cap the 4-path engines lost 2-8 % to the side stream: their aggregation launch is bound by the W-step
-        # chain of the horizontal scans, which the side stream's kernels slow down.)
-        # overlap="deferred": the plane stages of batch i are enqueued by the NEXT process_batch call (or flush()), on the
-        # side stream, gated behind the aggregation of batch i+1 (cart_compute_disparity_batch_gated): they then run beside
-        # the HBM-bound WTA of batch i+1 instead of beside its aggregation.  process_batch returns the outputs of the
-        # PREVIOUS batch (None on the first call); flush() returns those of the last one.  Never chosen by "auto" (it changes
-        # what process_batch returns); worth 3 % more than the plain side stream where the aggregation is latency-bound (D=64 / 4 paths: 13.4 k pairs/s).
+        # overlap=True ("auto" = on): the plane stages of batch i run on a side stream while the main stream already computes
+        # the disparity of batch i+1 (the plane stages are short, latency-bound launches that leave the GPU mostly idle).
+        # The side stream keeps the batches in order, so the plane-parameter schedule still sees the frames in id order.
+        # The outputs are then produced on `self.side`: synchronise (or wait for out["done"]) before reading them on
+        # another stream.  Needs engine max_inflight >= 2 * batch.  Measured (ms per 16-pair step, one stream / side stream):
+        # D=128 P=8 3.20 / 3.02, D=256 P=4 3.07 / 2.98, D=128 P=4 1.80 / 1.74, 1920x1080 D=256 P=8 (4 pairs) 6.13 / 5.99,
+        # D=64 P=4 1.28 / 1.24.  (Two further layouts -- plane stages gated behind the next batch's aggregation; census and
+        # post stages on streams of their own -- measured level or slower in round 2 and were removed: DESIGN.md appendix.)
         if overlap == "auto":
             overlap = True
-        self.deferred = overlap == "deferred"
-        self._pending = None
         self.side = torch.cuda.Stream() if overlap else None
-        # split_stages (with a side stream, not deferred): the main stream carries only aggregation + WTA; the stages after the
-        # WTA join the plane stages on the side stream, and -- when the caller says where the inputs are complete
-        # (process_batch(..., inputs_ready=event)) -- the census of batch i+1 runs on a third stream beside the WTA of batch i
-        # (cart_compute_disparity_batch_streams).  Off by default: measured (profiles/tools/r02_split.sh, three A/B pairs per
-        # configuration) it gains 1-4 % at D=64 / 4 paths and loses 1-3 % at D=128 / 8 paths, D=256 / 4 paths and 1920x1080 --
-        # the short kernels cost the two long launches more beside them than they cost in front of them.
-        self.split_stages = bool(overlap) and not self.deferred and split_stages
-        self.pre = torch.cuda.Stream() if self.split_stages else None
+        self._seq = None   # SequencePipeliner, created by the first sequence call
 
-    def process_batch(self, left, right, inputs_ready=None):
+    def process_batch(self, left, right, inputs_ready=None, n_global=None):
         """inputs_ready: a torch.cuda.Event after which `left` / `right` are complete (the upload's event, or one recorded
-        when resident inputs were written).  Without it the inputs are taken to be complete on the current stream only."""
-        if self.side is None:
-            return self._process_batch(left, right)
+        when resident inputs were written).  Without it the inputs are taken to be complete on the current stream only.
+        n_global: frames of the global batch when the ranks hold unequal shares (sequence mode); default n * world."""
         import torch
         main = torch.cuda.current_stream()
-        if self.split_stages:
-            census_stream = None
-            if inputs_ready is not None:
-                self.pre.wait_event(inputs_ready)
-                left.record_stream(self.pre); right.record_stream(self.pre)
-                census_stream = self.pre
-            disp = self.engine.compute_disparity(left, right, census_stream=census_stream, tail_stream=self.side)
-            disp.record_stream(self.side)
-            with torch.cuda.stream(self.side):   # post + interpolate of this batch are already queued there
-                out = self._process_batch(left, right, disp)
-                out["done"] = self.side.record_event()
-            return out
-        if self.deferred:
-            disp = self.engine.compute_disparity(left, right, gated_stream=self.side)
-            out = self._finish_pending()
-            self._pending = (left, right, disp, main.record_event())
-            return out
-        disp = self.engine.compute_disparity(left, right)
+        if inputs_ready is not None:
+            main.wait_event(inputs_ready)
+        if self.side is None:
+            return self._process_batch(left, right, None, n_global)
+        disp = self.engine.compute_disparity(left, right) if left.shape[0] else None
         self.side.wait_stream(main)
-        disp.record_stream(self.side)
+        if disp is not None:
+            disp.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            out = self._process_batch(left, right, disp)
+            out = self._process_batch(left, right, disp, n_global)
             out["done"] = self.side.record_event()
         return out
 
-    def _finish_pending(self):
-        if self._pending is None:
-            return None
-        left, right, disp, ready = self._pending
-        self._pending = None
-        self.side.wait_event(ready)   # the batch's disparity (long past when a later batch's gate is already in the queue)
-        for t in (left, right, disp):
-            t.record_stream(self.side)
+    # ---- batched-sequence mode -------------------------------------------------------------------------------------
+    def _sequencer(self, channels):
         import torch
-        with torch.cuda.stream(self.side):
-            out = self._process_batch(left, right, disp)
-            out["done"] = self.side.record_event()
-        return out
+        e = self.engine
+        shape = (e.height, e.width) if channels == 1 else (e.height, e.width, 3)
+        if self._seq is None or self._seq.shape != shape:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._seq = SequencePipeliner(lambda l, r, n_total: self.process_batch(l, r, n_global=n_total), shape, self.group, dev)
+        return self._seq
 
-    def flush(self):
-        """overlap="deferred": enqueue the plane stages of the batch that is still pending and return its outputs
-        (None when nothing is pending or in the other modes, whose process_batch has already returned everything)."""
-        return self._finish_pending() if self.deferred else None
+    def submit_sequence(self, left, right, n_total, root=0, channels=1, keys=("disparity", "planes")):
+        """Pipelined batched-sequence mode: a sequence that lives on `root` ([n_total, H, W] gray or, with channels=3,
+        [n_total, H, W, 3] BGR; None elsewhere) is dealt out, this rank's share is enqueued as one batch, and a
+        SequenceHandle is returned at once; the gather of the PREVIOUS sequence is posted by this call, behind this
+        sequence's scatter (SequencePipeliner).  Frame ids continue from the previous call like process_batch's.  Needs
+        torch.distributed (any world size, one rank included) -- process_sequence takes the no-exchange shortcut itself."""
+        return self._sequencer(channels).submit(left, right, n_total, root, keys)
 
     def process_sequence(self, left, right, n_total, root=0, channels=1, keys=("disparity", "planes")):
-        """A sequence that lives on `root` ([n_total, H, W] gray or, with channels=3, [n_total, H, W, 3] BGR; None elsewhere): scatter the frames, run this rank's
-        share as one batch, gather the named outputs back on `root` in sequence order (None on the other ranks).  With
-        world == 1 this is process_batch.  Frame ids continue from the previous call like process_batch's."""
+        """Unpipelined form: submit_sequence(...).result().  With world == 1 (and no always_exchange) this is process_batch."""
         import torch
-        if self.deferred and self._pending is not None:
-            raise ValueError("process_sequence returns the outputs of the frames it is given: flush() the pending batch first")
         if self.world == 1 and not self.always_exchange:
-            out = self._batch_now(left, right)
+            out = self.process_batch(left, right)
             torch.cuda.current_stream().wait_event(out["done"]) if "done" in out else None
             return {k: out[k] for k in keys}
-        e = self.engine
-        dev = torch.device("cuda", torch.cuda.current_device())
-        per_frame = (e.height, e.width) if channels == 1 else (e.height, e.width, 3)
-        l = scatter_sequence(left, n_total, (per_frame, torch.uint8, dev), root, self.group)
-        r = scatter_sequence(right, n_total, (per_frame, torch.uint8, dev), root, self.group)
-        out = self._batch_now(l, r)
-        if "done" in out:
-            torch.cuda.current_stream().wait_event(out["done"])
-        return {k: gather_sequence(out[k], root, self.group) for k in keys}
+        return self.submit_sequence(left, right, n_total, root, channels, keys).result(block=False)
 
-    def _batch_now(self, left, right):
-        """process_batch + (deferred mode) flush: the outputs of exactly these frames."""
-        out = self.process_batch(left, right)
-        return self.flush() if self.deferred else out
+    def drain(self):
+        if self._seq is not None:
+            self._seq.drain()
 
-    def _process_batch(self, left, right, disp=None):
-        """left/right: uint8 [n,h,w(,3)] on the GPU: this rank's n frames of a global batch of
-        n*world frames (interleaved ids).  -> dict(disparity, planes, ids, n_components, params)."""
+    # ---- one rank's share of a global batch ---------------------------------------------------------------------------
+    def _gather_hists(self, n, n_global):
+        """All-gather of the per-frame histograms (the path's only exchange step) into frame-id order: [n_global, 256]
+        (device tensor; on gloo via host copies).  Ranks with a short share pad theirs with zero rows up to the longest."""
+        import torch
+        dist = torch.distributed
+        n_max = -(-n_global // self.world)
+        src = self._hist
+        if n < n_max:
+            src = torch.cat([src, src.new_zeros((n_max - n, 256))])
+        on_host = dist.get_backend(self.group) == "gloo"   # RCCL gathers device tensors; gloo (CPU rehearsals) host copies
+        src = src.cpu() if on_host else src.contiguous()
+        allh = torch.empty((self.world * n_max, 256), dtype=torch.int32, device=src.device)
+        _guarded("all_gather_into_tensor(histograms)", self.group, lambda: dist.all_gather_into_tensor(allh, src, group=self.group))
+        # [rank][j] -> id order j*world + rank; padded rows are exactly the ids >= n_global
+        return allh.view(self.world, n_max, 256).permute(1, 0, 2).reshape(n_max * self.world, 256)[:n_global].contiguous().to(self._hist.device)
+
+    def _process_batch(self, left, right, disp=None, n_global=None):
+        """left/right: uint8 [n,h,w(,3)] on the GPU: this rank's n frames of a global batch of n_global frames (default
+        n*world; interleaved ids, frame k of the batch on rank k mod world).  -> dict(disparity, planes, ids, n_components, params)."""
         import torch
         eng = self.engine
         n = left.shape[0]
-        if disp is None:
-            disp = eng.compute_disparity(left, right)
+        if n_global is None:
+            n_global = n * self.world
+        if n != share_of(n_global, self.rank, self.world):
+            raise ValueError(f"rank {self.rank} holds {n} frames of a global batch of {n_global}")
+        dev = left.device
+        exchange = self.world > 1 or self.always_exchange
         if self._hist is None or self._hist.shape[0] != n:
-            self._hist = torch.empty((n, 256), dtype=torch.int32, device=left.device)
+            self._hist = torch.empty((n, 256), dtype=torch.int32, device=dev)
         self._hist.zero_()
-        deriv = eng.plane_derivative_hist(disp, self._hist, per_frame_hist=True)
+        if n:
+            if disp is None:
+                disp = eng.compute_disparity(left, right)
+            deriv = eng.plane_derivative_hist(disp, self._hist, per_frame_hist=True)
+        else:   # fewer frames than ranks: this rank only joins the exchange
+            disp = torch.empty((0, eng.height, eng.width), dtype=torch.int16, device=dev)
+            deriv = disp
         kept = self._hist.clone() if self.keep_hists else None
+        static = self.schedule.provider == "static"
         if self.dev_schedule is not None:
-            hists = self._hist
-            if (self.world > 1 or self.always_exchange) and self.schedule.provider != "static":
-                on_host = torch.distributed.get_backend(self.group) == "gloo"
-                src = self._hist.cpu() if on_host else self._hist
-                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=src.device)
-                torch.distributed.all_gather_into_tensor(allh, src, group=self.group)
-                hists = allh.view(self.world, n, 256).permute(1, 0, 2).reshape(n * self.world, 256).contiguous().to(left.device)
-            if self.world > 1 and self.schedule.provider == "static":
-                hists = self._hist.new_zeros((n * self.world, 256))
+            if exchange and not static:
+                hists = self._gather_hists(n, n_global)
+            elif exchange:
+                hists = self._hist.new_zeros((n_global, 256))
+            else:
+                hists = self._hist
             allp = self.dev_schedule.advance(self.next_id, hists)
             mine = allp[self.rank::self.world].contiguous() if self.world > 1 else allp
-            self.next_id += n * self.world
-            planes = eng.plane_classify_dev(deriv, mine)
-            out = dict(disparity=disp, planes=planes, params=mine)
-            if kept is not None:
-                out["hists"] = kept
-            if self.with_ccl:
-                out["ids"], out["n_components"] = eng.plane_ccl(planes)
-                out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
-            return out
-        if self.schedule.provider == "static":
-            per_frame = [self.schedule.params] * n
+            planes = eng.plane_classify_dev(deriv, mine) if n else torch.empty((0, eng.height, eng.width), dtype=torch.uint8, device=dev)
+            params = mine
         else:
-            if self.world > 1 or self.always_exchange:
-                # RCCL gathers device tensors; the gloo backend (CPU rehearsals) gathers host copies
-                on_host = torch.distributed.get_backend(self.group) == "gloo"
-                src = self._hist.cpu() if on_host else self._hist
-                allh = torch.empty((self.world * n, 256), dtype=torch.int32, device=src.device)
-                torch.distributed.all_gather_into_tensor(allh, src, group=self.group)
-                # [rank][k] -> id order k*world + rank
-                hists = allh.view(self.world, n, 256).permute(1, 0, 2).reshape(n * self.world, 256).cpu().numpy()
+            if static:
+                per_frame = [self.schedule.params] * n
             else:
-                hists = self._hist.cpu().numpy()
-            allp = self.schedule.advance(self.next_id, hists)
-            per_frame = allp[self.rank::self.world]
-        self.next_id += n * self.world
-        planes = eng.plane_classify(deriv, list(per_frame) if n > 1 else per_frame[0])
-        out = dict(disparity=disp, planes=planes, params=per_frame)
+                hists = (self._gather_hists(n, n_global) if exchange else self._hist).cpu().numpy()
+                allp = self.schedule.advance(self.next_id, hists)
+                per_frame = allp[self.rank::self.world]
+            planes = eng.plane_classify(deriv, list(per_frame) if n > 1 else per_frame[0]) if n else torch.empty((0, eng.height, eng.width), dtype=torch.uint8, device=dev)
+            params = per_frame
+        self.next_id += n_global
+        out = dict(disparity=disp, planes=planes, params=params)
         if kept is not None:
             out["hists"] = kept
-        if self.with_ccl:
+        if self.with_ccl and n:
             out["ids"], out["n_components"] = eng.plane_ccl(planes)
             out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
         return out

@@ -35,9 +35,6 @@ int fail(const std::string &msg) {
 
 struct Slot {
     bool busy = false;
-    // stage markers of the multi-stream entry points (lazily created): [0] "aggregation of this lease has finished"
-    // (cart_compute_disparity_batch_gated), [1] census done on the census stream, [2] WTA done (the tail stream waits for it)
-    hipEvent_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;          // recorded only on the FIRST slot of a lease ...
     int owner = -1;                     // ... every slot of the lease points at that slot
     hipStream_t last_stream = nullptr;
@@ -214,8 +211,9 @@ Options snapshot_options(const cart_engine *e) { return Options{e->opt_plan, e->
 int plan_for(const cart_engine *e, const Options &o, int n) {
     if (o.plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
     if (n < o.plan_min_frames) return CART_PLAN_SLABS;
-    // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP
-    if (o.plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255)) return CART_PLAN_FUSED_UP;
+    // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP.  So do
+    // images whose sink offset does not fit the sweep's 32-bit lane offsets (pairs_offsets_fit).
+    if (o.plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255 && pairs_offsets_fit(e->g))) return CART_PLAN_FUSED_UP;
     return o.plan;
 }
 
@@ -350,8 +348,6 @@ void cart_engine_destroy(cart_engine *e) {
         if (b) (void)hipFree(b);
     for (auto &s : e->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
-        for (auto &ev : s.aux)
-            if (ev) (void)hipEventDestroy(ev);
     }
     for (auto &r : e->ring)
         for (auto &ev : r.ev)
@@ -417,6 +413,7 @@ int cart_engine_device_status(cart_engine *e, unsigned *status) {
     HIP_TRY(hipSetDevice(e->params.device_id));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(status, e->dev_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (*status) HIP_TRY(hipMemset(e->dev_status, 0, sizeof(unsigned)));   // read-and-clear: a report covers the calls since the last query
     return 0;
 }
 
@@ -490,14 +487,7 @@ struct FrameSet {
     }
 };
 
-// Streams of one call: `main` carries aggregation + WTA; the census may run on `census` (a stream on which the inputs are
-// complete), the stages after the WTA on `tail`; `gated` is made to wait for the end of the aggregation.  NULL = main.
-struct StreamSet {
-    void *main = nullptr, *census = nullptr, *tail = nullptr, *gated = nullptr;
-};
-
-int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int channels, const StreamSet &ss) {
-    void *stream_ = ss.main;
+int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int channels, void *stream_) {
     if (!e) return fail("engine is NULL");
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (channels != 1 && channels != 3) return fail("channels must be 1 (gray) or 3 (BGR)");
@@ -526,23 +516,9 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
             e->pair_xch = xch;
         }
     }
-    hipStream_t gated = static_cast<hipStream_t>(ss.gated), census_st = static_cast<hipStream_t>(ss.census), tail_st = static_cast<hipStream_t>(ss.tail);
-    if (gated == stream) gated = nullptr;
-    if (!ss.census || census_st == stream) census_st = nullptr;   // nullptr below = "on the main stream"
-    if (!ss.tail || tail_st == stream) tail_st = nullptr;
-    const bool own_census = ss.census && census_st, own_tail = ss.tail && tail_st;
-    // The lease is taken on the first stream that touches the slots (its cross-stream waits go there) and released on the last
     Lease l;
-    if (acquire(e, n_frames, own_census ? census_st : stream, &l)) return -1;
+    if (acquire(e, n_frames, stream, &l)) return -1;
     g_last_slot = l.s0;
-    hipError_t gate_err = hipSuccess;
-    // marker k of the launch sequence that starts at slot `slot`: recorded on `from`, awaited by `to`
-    auto hand_over = [&](int slot, int k, hipStream_t from, hipStream_t to) {
-        hipEvent_t &ev = e->slots[slot].aux[k];
-        if (gate_err == hipSuccess && !ev) gate_err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (gate_err == hipSuccess) gate_err = hipEventRecord(ev, from);
-        if (gate_err == hipSuccess) gate_err = hipStreamWaitEvent(to, ev, 0);
-    };
     TimingRec *rec = nullptr;
     if (opt.timing) {
         std::lock_guard<std::mutex> lk(e->mu);
@@ -566,8 +542,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         TimingRec *rec_save = rec;
         if (!timed) rec = nullptr;
         STAGE("census");
-        launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, own_census ? census_st : st);
-        if (own_census) hand_over((int)s0, 1, census_st, st);
+        launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
         const int launch_plan = plan_for(e, opt, n);
         const bool pairs = launch_plan == CART_PLAN_PAIRS && e->pair_xch;
         const bool fused = launch_plan == CART_PLAN_FUSED_UP && e->rv_partial;
@@ -593,15 +568,10 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         AggArgs a = pairs ? e->agg_pairs : fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
-        if (gated && f0 + n >= n_frames) hand_over(l.s0, 0, st, gated);   // last launch sequence of the call: the aggregation of every frame is behind this point
         STAGE("wta");
         if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq, n, st);
         else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
         else launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
-        if (own_tail) {   // the stages after the WTA go to the caller's tail stream
-            hand_over((int)s0, 2, st, tail_st);
-            st = tail_st; stream = tail_st;
-        }
         STAGE("post");
         if (!smooth) {
             launch_post(wl, rpk, gl, o, g, n, st);
@@ -630,40 +600,11 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     const int chunk = fr.lefts ? std::min(opt.chunk_frames, kLaunchFrames) : opt.chunk_frames;  // pointer tables hold kLaunchFrames entries
     for (int f0 = 0; f0 < n_frames; f0 += chunk) enqueue(f0, std::min(chunk, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
-    l.stream = own_tail ? tail_st : stream;   // the lease's last work: its completion marker is recorded there
     release(l);
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
-    if (gate_err != hipSuccess) return fail(std::string("stream hand-over failed: ") + hipGetErrorString(gate_err));
     return 0;
 }
 }  // namespace
-
-int cart_compute_disparity_batch_streams(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
-                                         size_t left_frame_stride, const uint8_t *right, size_t right_step,
-                                         size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
-                                         size_t out_frame_stride, void *stream, void *census_stream, void *tail_stream,
-                                         void *gated_stream) {
-    if (!left || !right || !out) return fail("NULL image pointer");
-    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
-    FrameSet fr{};
-    fr.left = left; fr.right = right; fr.left_fs = left_frame_stride; fr.right_fs = right_frame_stride; fr.out = out; fr.out_fs = out_frame_stride;
-    fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
-    StreamSet ss; ss.main = stream; ss.census = census_stream; ss.tail = tail_stream; ss.gated = gated_stream;
-    return compute_disparity_impl(e, n_frames, fr, channels, ss);
-}
-
-int cart_compute_disparity_batch_gated(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
-                                       size_t left_frame_stride, const uint8_t *right, size_t right_step,
-                                       size_t right_frame_stride, int channels, int16_t *out, size_t out_step,
-                                       size_t out_frame_stride, void *stream, void *gated_stream) {
-    if (!left || !right || !out) return fail("NULL image pointer");
-    if (out_frame_stride & 1) return fail("out_frame_stride must be even");
-    FrameSet fr{};
-    fr.left = left; fr.right = right; fr.left_fs = left_frame_stride; fr.right_fs = right_frame_stride; fr.out = out; fr.out_fs = out_frame_stride;
-    fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
-    StreamSet ss; ss.main = stream; ss.gated = gated_stream;
-    return compute_disparity_impl(e, n_frames, fr, channels, ss);
-}
 
 int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *left, size_t left_step,
                                  size_t left_frame_stride, const uint8_t *right, size_t right_step,
@@ -674,8 +615,7 @@ int cart_compute_disparity_batch(cart_engine *e, int n_frames, const uint8_t *le
     FrameSet fr{};
     fr.left = left; fr.right = right; fr.left_fs = left_frame_stride; fr.right_fs = right_frame_stride; fr.out = out; fr.out_fs = out_frame_stride;
     fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
-    StreamSet ss; ss.main = stream;
-    return compute_disparity_impl(e, n_frames, fr, channels, ss);
+    return compute_disparity_impl(e, n_frames, fr, channels, stream);
 }
 
 int cart_compute_disparity_multi(cart_engine *e, int n_frames, const uint8_t *const *left, size_t left_step,
@@ -689,8 +629,7 @@ int cart_compute_disparity_multi(cart_engine *e, int n_frames, const uint8_t *co
     FrameSet fr{};
     fr.lefts = left; fr.rights = right; fr.outs = out;
     fr.left_step = left_step; fr.right_step = right_step; fr.out_step = out_step;
-    StreamSet ss; ss.main = stream;
-    return compute_disparity_impl(e, n_frames, fr, channels, ss);
+    return compute_disparity_impl(e, n_frames, fr, channels, stream);
 }
 
 int cart_compute_disparity(cart_engine *e, const uint8_t *left, size_t left_step, const uint8_t *right,

@@ -895,7 +895,8 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     const uint32_t *pw = a.cen_r + uniform(cen_off - g.min_disp - (D - 1));
     const uint32_t *pl = a.cen_l + uniform(cen_off);
     // slab addressing: uniform base of the wave's first column (clamped into the image) + lane offset; columns past the
-    // image store into the same cell of a slab this plan never reads
+    // image store into the same cell of a slab this plan never reads.  The sink offset is a 32-bit lane offset: the
+    // engine only takes this plan when pairs_offsets_fit(g) (engine_internal.h), i.e. 4 slabs + a row stay below 2^32
     const int xbase = min(xw0, g.w - 1), xc = min(x, g.w - 1);
     uint8_t *po = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.out_path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + xbase) * D);
     unsigned lo_l = (unsigned)pg * 4u;

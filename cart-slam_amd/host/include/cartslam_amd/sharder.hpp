@@ -3,8 +3,11 @@
 // the C ABI (disparity -> plane derivative + per-frame histogram), the histograms are all-gathered, every GPU replays the
 // plane-parameter schedule of DisparityPlaneSegmentationModule::updatePlaneParameters (planeseg.cu:379-403) for the whole
 // sequence and classifies its own frames, and disparity + planes come back to GPU 0 in sequence order.
-// Transport: RCCL (ncclCommInitAll, one communicator per GPU).  Scatter and gather are grouped ncclSend / ncclRecv -- GPU 0
-// has a direct xGMI link to every peer, so no ring is involved -- the histogram exchange is one ncclAllGather (1 KB per frame).
+// Transport: RCCL (ncclCommInitAll, one communicator per GPU and purpose).  Scatter and gather are grouped ncclSend / ncclRecv,
+// ONE per peer and image kind (GPU 0 packs a peer's frames into a staging area first) -- GPU 0 has a direct xGMI link to every
+// peer, so no ring is involved -- the histogram exchange is one ncclAllGather (1 KB per frame).
+// Sequences are double-buffered: every GPU has a copy stream beside its compute stream, submit(i+1) posts the scatter of
+// sequence i+1, then the gather of sequence i, then the kernels of i+1, so that the transfers run beside the kernels.
 // The reference has no multi-GPU mode (include/cartslam.hpp:4 is frame pipelining on one GPU): this is new functionality.
 // The same sharding over torch.distributed lives in cartslam/pipeline.py and must give identical results.
 #pragma once
@@ -21,6 +24,7 @@ namespace cart {
 class FrameSharder {
    public:
     // devices: HIP device ids, devices[0] holds the sequence and receives the results.  params.max_inflight is overwritten.
+    // framesPerGpu: the largest share of one sequence a GPU may hold (capacity() = framesPerGpu * gpus()).
     FrameSharder(const std::vector<int> &devices, cart_engine_params params, int framesPerGpu, int updateInterval = 30, int resetInterval = 10);
     ~FrameSharder();
     FrameSharder(const FrameSharder &) = delete;
@@ -28,17 +32,32 @@ class FrameSharder {
 
     int gpus() const { return (int)ranks.size(); }
     int capacity() const { return framesPerGpu * gpus(); }
+    // frames of an nFrames-sequence that land on GPU `rank`: the first nFrames % gpus() GPUs hold one frame more
+    static int shareOf(int nFrames, int rank, int gpus) { return nFrames > rank ? (nFrames - rank + gpus - 1) / gpus : 0; }
 
-    // left / right: gray frames [nFrames][h][w], tight, in the memory of devices[0]; nFrames must be a positive multiple of
-    // gpus() and <= capacity().  Frame k gets id firstId + k (ids are 1-based and must continue from the previous call: the
-    // schedule's histogram is cumulative).  disparity [nFrames][h][w] s16 and planes [nFrames][h][w] u8: tight, devices[0].
-    // Blocks until the results are in place.  Throws std::runtime_error on any failure.
+    // Enqueues one sequence and returns at once.  left / right: gray frames [nFrames][h][w], tight, in the memory of
+    // devices[0], complete on `callerStream` (a hipStream_t of devices[0]; nullptr = its null stream) when the call is made:
+    // the sharder's own streams are non-blocking, so it records an event there and waits for it.  1 <= nFrames <= capacity(),
+    // any remainder modulo gpus().  Frame k gets id firstId + k (ids are 1-based and continue from the previous call: the
+    // schedule's histogram is cumulative).  disparity [nFrames][h][w] s16 and planes [nFrames][h][w] u8: tight, devices[0];
+    // they are complete after the wait() that follows (at most two sequences are in flight: a third submit first waits for
+    // the oldest).  The input and output buffers of a sequence must stay untouched until then.
+    // Throws std::runtime_error on any failure.
+    void submit(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes, void *callerStream = nullptr);
+    // Posts the gather of the sequence submitted last and blocks until every submitted sequence's results are in place.
+    // A GPU whose work does not finish within timeoutSeconds makes this throw, naming that GPU and its RCCL error state.
+    void wait(double timeoutSeconds = 120.0);
+    // submit + wait
     void processSequence(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes);
 
    private:
     struct Rank;
+    struct Pending { int nFrames = 0; int16_t *disparity = nullptr; uint8_t *planes = nullptr; int buf = 0; bool live = false; };
+    void postGather(const Pending &p);
     std::vector<std::unique_ptr<Rank>> ranks;
     const int framesPerGpu, width, height;
     int nextId = 1;
+    long long submitted = 0;
+    Pending pending;   // kernels enqueued, gather not yet posted
 };
 }  // namespace cart

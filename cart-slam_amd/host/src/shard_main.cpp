@@ -1,9 +1,13 @@
 // cart_shard_amd <left.bin> <right.bin> <width> <height> <frames> <num_disparities> <paths> <gpus> <frames per call> <out dir> [update_interval reset_interval]
 // Batched-sequence mode of the C++ host (cartslam_amd/sharder.hpp): the gray frames of <left.bin>/<right.bin> (u8, tight) are
-// uploaded to GPU 0, dealt out over <gpus> GPUs with RCCL <frames per call> at a time, and disparity.bin (s16) / planes.bin
-// (u8) are written to <out dir>.  Prints pairs/s of the second pass over the sequence (first pass = warm-up + the dumped results).
+// uploaded to GPU 0, dealt out over <gpus> GPUs with RCCL <frames per call> at a time (any remainder: the first GPUs hold one
+// frame more, the last call is shorter), and disparity.bin (s16) / planes.bin (u8) are written to <out dir>.
+// Two passes over the sequence, each with a fresh sharder (frame ids start over): pass 0 one call at a time (submit + wait),
+// pass 1 pipelined (every call submitted, one wait at the end: the scatter of call i+1 and the gather of call i-1 run beside
+// the kernels of call i).  The two passes must agree byte for byte (exit 2 otherwise); the files hold the pipelined pass.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +29,7 @@ int main(int argc, char **argv) {
         const int ui = argc > 11 ? std::atoi(argv[11]) : 30, ri = argc > 12 ? std::atoi(argv[12]) : 10;
         int have = 0;
         if (hipGetDeviceCount(&have) != hipSuccess || have < gpus) throw std::runtime_error("this box has " + std::to_string(have) + " GPUs, " + std::to_string(gpus) + " asked for");
-        if (n % perCall || perCall % gpus) throw std::runtime_error("frames must be a multiple of frames per call, and that a multiple of the GPUs");
+        if (n < 1 || perCall < 1) throw std::runtime_error("frames and frames per call must be positive");
         const size_t npx = (size_t)w * h;
         std::vector<uint8_t> hl(npx * n), hr(npx * n);
         for (auto &pr : {std::make_pair(argv[1], &hl), std::make_pair(argv[2], &hr)}) {
@@ -37,27 +41,40 @@ int main(int argc, char **argv) {
         p.width = w; p.height = h; p.num_disparities = D; p.paths = P; p.smoothing_radius = 2; p.smoothing_iterations = 1;
         std::vector<int> devices;
         for (int i = 0; i < gpus; ++i) devices.push_back(i);
-        std::vector<int16_t> hd(npx * n);
-        std::vector<uint8_t> hp(npx * n);
-        double pairsPerSecond = 0;
+        std::vector<int16_t> hd(npx * n), hd0;
+        std::vector<uint8_t> hp(npx * n), hp0;
+        double pairsPerSecond[2] = {0, 0};
         for (int pass = 0; pass < 2; ++pass) {   // fresh sharder per pass: frame ids (and the cumulative histogram) start over
-            cart::FrameSharder sharder(devices, p, perCall / gpus, ui, ri);
+            cart::FrameSharder sharder(devices, p, (perCall + gpus - 1) / gpus, ui, ri);
             if (hipSetDevice(0) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
             uint8_t *dl, *dr, *dp; int16_t *dd;
             if (hipMalloc((void **)&dl, npx * n) || hipMalloc((void **)&dr, npx * n) || hipMalloc((void **)&dp, npx * n) || hipMalloc((void **)&dd, npx * n * 2))
                 throw std::runtime_error("hipMalloc failed");
             (void)hipMemcpy(dl, hl.data(), npx * n, hipMemcpyHostToDevice);
             (void)hipMemcpy(dr, hr.data(), npx * n, hipMemcpyHostToDevice);
+            (void)hipDeviceSynchronize();
             const auto t0 = std::chrono::steady_clock::now();
-            for (int f0 = 0; f0 < n; f0 += perCall) sharder.processSequence(dl + f0 * npx, dr + f0 * npx, perCall, dd + f0 * npx, dp + f0 * npx);
-            pairsPerSecond = n / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (int f0 = 0; f0 < n; f0 += perCall) {
+                const int cnt = std::min(perCall, n - f0);
+                if (pass == 0) sharder.processSequence(dl + f0 * npx, dr + f0 * npx, cnt, dd + f0 * npx, dp + f0 * npx);
+                else sharder.submit(dl + f0 * npx, dr + f0 * npx, cnt, dd + f0 * npx, dp + f0 * npx);
+            }
+            sharder.wait();
+            pairsPerSecond[pass] = n / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            (void)hipSetDevice(0);
             (void)hipMemcpy(hd.data(), dd, npx * n * 2, hipMemcpyDeviceToHost);
             (void)hipMemcpy(hp.data(), dp, npx * n, hipMemcpyDeviceToHost);
             (void)hipFree(dl); (void)hipFree(dr); (void)hipFree(dp); (void)hipFree(dd);
+            if (pass == 0) { hd0 = hd; hp0 = hp; }
+        }
+        if (hd0 != hd || hp0 != hp) {
+            std::cerr << "fatal: the pipelined pass differs from the one-call-at-a-time pass\n";
+            return 2;
         }
         std::ofstream(out + "/disparity.bin", std::ios::binary).write(reinterpret_cast<const char *>(hd.data()), (std::streamsize)(npx * n * 2));
         std::ofstream(out + "/planes.bin", std::ios::binary).write(reinterpret_cast<const char *>(hp.data()), (std::streamsize)(npx * n));
-        std::cout << "frames " << n << " gpus " << gpus << " frames_per_call " << perCall << " pairs_per_s " << pairsPerSecond << "\n";
+        std::cout << "frames " << n << " gpus " << gpus << " frames_per_call " << perCall << " pairs_per_s " << pairsPerSecond[1]
+                  << " pairs_per_s_one_call_at_a_time " << pairsPerSecond[0] << "\n";
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "fatal: " << e.what() << "\n";

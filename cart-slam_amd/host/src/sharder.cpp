@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <stdexcept>
+#include <thread>
 
 namespace cart {
 namespace {
@@ -19,33 +21,67 @@ void cartOk(int rc, cart_engine *e, const char *what) {
 template <typename T>
 T *devAlloc(size_t n) {
     void *p = nullptr;
-    hipOk(hipMalloc(&p, n * sizeof(T)), "hipMalloc");
+    hipOk(hipMalloc(&p, (n ? n : 1) * sizeof(T)), "hipMalloc");
     return static_cast<T *>(p);
 }
+// communicators of one ncclCommInitAll: the ones no Rank has taken over yet are destroyed on the way out of a failed constructor
+struct CommSet {
+    std::vector<ncclComm_t> comms;
+    explicit CommSet(const std::vector<int> &devices) : comms(devices.size(), nullptr) {
+        ncclOk(ncclCommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+    }
+    ncclComm_t take(int r) { ncclComm_t c = comms[r]; comms[r] = nullptr; return c; }
+    ~CommSet() {
+        for (ncclComm_t c : comms)
+            if (c) (void)ncclCommDestroy(c);
+    }
+};
+// an exception between ncclGroupStart and ncclGroupEnd must not leave the group open
+struct NcclGroup {
+    bool open = true;
+    NcclGroup() { ncclOk(ncclGroupStart(), "ncclGroupStart"); }
+    void end() { open = false; ncclOk(ncclGroupEnd(), "ncclGroupEnd"); }
+    ~NcclGroup() { if (open) (void)ncclGroupEnd(); }
+};
 }  // namespace
 
 struct FrameSharder::Rank {
     int device = 0;
     cart_engine *engine = nullptr;
     cart_plane_schedule *schedule = nullptr;
-    hipStream_t stream = nullptr;
-    ncclComm_t comm = nullptr;
-    uint8_t *left = nullptr, *right = nullptr, *planes = nullptr;   // this GPU's share, [framesPerGpu][h][w]
-    int16_t *disparity = nullptr, *derivative = nullptr;
-    int32_t *hist = nullptr;          // [framesPerGpu][256]
-    int32_t *histByRank = nullptr;    // [gpus][framesPerGpu][256], as the all-gather delivers them
-    int32_t *histById = nullptr;      // [capacity][256], frame-id order
+    hipStream_t compute = nullptr, copy = nullptr;   // kernels + histogram all-gather / scatter + gather
+    ncclComm_t commCompute = nullptr, commCopy = nullptr;   // one communicator per stream: operations of one communicator are ordered
+    // two buffer sets (sequence i uses set i & 1): this GPU's share, [framesPerGpu][h][w]
+    uint8_t *left[2] = {}, *right[2] = {}, *planes[2] = {};
+    int16_t *disparity[2] = {}, *derivative[2] = {};
+    int32_t *hist[2] = {};          // [framesPerGpu][256]
+    int32_t *histByRank = nullptr;  // [gpus][framesPerGpu][256], as the all-gather delivers them
+    int32_t *histById = nullptr;    // [capacity][256], frame-id order
     cart_plane_params *paramsAll = nullptr, *paramsMine = nullptr;
+    // GPU 0 only: peers' frames packed per peer ([gpus][framesPerGpu][h][w]) on their way out / back
+    uint8_t *stageLeft[2] = {}, *stageRight[2] = {}, *stagePlanes[2] = {};
+    int16_t *stageDisparity[2] = {};
+    hipEvent_t scattered[2] = {}, computed[2] = {}, gathered[2] = {}, inputsReady = nullptr;
     ~Rank() {
         (void)hipSetDevice(device);
-        if (stream) (void)hipStreamSynchronize(stream);
+        for (hipStream_t s : {compute, copy})
+            if (s) (void)hipStreamSynchronize(s);
         if (schedule) cart_plane_schedule_destroy(schedule);
         if (engine) cart_engine_destroy(engine);
-        for (void *p : {(void *)left, (void *)right, (void *)planes, (void *)disparity, (void *)derivative, (void *)hist, (void *)histByRank, (void *)histById,
-                        (void *)paramsAll, (void *)paramsMine})
+        for (int b = 0; b < 2; ++b) {
+            for (void *p : {(void *)left[b], (void *)right[b], (void *)planes[b], (void *)disparity[b], (void *)derivative[b], (void *)hist[b],
+                            (void *)stageLeft[b], (void *)stageRight[b], (void *)stagePlanes[b], (void *)stageDisparity[b]})
+                if (p) (void)hipFree(p);
+            for (hipEvent_t e : {scattered[b], computed[b], gathered[b]})
+                if (e) (void)hipEventDestroy(e);
+        }
+        for (void *p : {(void *)histByRank, (void *)histById, (void *)paramsAll, (void *)paramsMine})
             if (p) (void)hipFree(p);
-        if (comm) (void)ncclCommDestroy(comm);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (inputsReady) (void)hipEventDestroy(inputsReady);
+        for (ncclComm_t c : {commCompute, commCopy})
+            if (c) (void)ncclCommDestroy(c);
+        for (hipStream_t s : {compute, copy})
+            if (s) (void)hipStreamDestroy(s);
     }
 };
 
@@ -53,26 +89,38 @@ FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params p
     : framesPerGpu(framesPerGpu), width(params.width), height(params.height) {
     if (devices.empty() || framesPerGpu < 1) throw std::invalid_argument("FrameSharder needs at least one GPU and one frame per GPU");
     const int n = (int)devices.size();
-    const size_t npx = (size_t)width * height;
-    std::vector<ncclComm_t> comms(n);
-    ncclOk(ncclCommInitAll(comms.data(), n, devices.data()), "ncclCommInitAll");
+    const size_t npx = (size_t)width * height, share = (size_t)framesPerGpu * npx;
+    CommSet forCompute(devices), forCopy(devices);
     for (int r = 0; r < n; ++r) {
         auto rank = std::make_unique<Rank>();
         rank->device = devices[r];
-        rank->comm = comms[r];
+        rank->commCompute = forCompute.take(r);
+        rank->commCopy = forCopy.take(r);
         hipOk(hipSetDevice(devices[r]), "hipSetDevice");
-        hipOk(hipStreamCreateWithFlags(&rank->stream, hipStreamNonBlocking), "hipStreamCreate");
+        hipOk(hipStreamCreateWithFlags(&rank->compute, hipStreamNonBlocking), "hipStreamCreate");
+        hipOk(hipStreamCreateWithFlags(&rank->copy, hipStreamNonBlocking), "hipStreamCreate");
         params.device_id = devices[r];
         params.max_inflight = framesPerGpu;
         if (cart_engine_create(&params, &rank->engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
         cartOk(cart_plane_schedule_create(rank->engine, /*histogram_peak*/ 1, nullptr, updateInterval, resetInterval, &rank->schedule), rank->engine,
                "cart_plane_schedule_create");
-        rank->left = devAlloc<uint8_t>(framesPerGpu * npx);
-        rank->right = devAlloc<uint8_t>(framesPerGpu * npx);
-        rank->planes = devAlloc<uint8_t>(framesPerGpu * npx);
-        rank->disparity = devAlloc<int16_t>(framesPerGpu * npx);
-        rank->derivative = devAlloc<int16_t>(framesPerGpu * npx);
-        rank->hist = devAlloc<int32_t>((size_t)framesPerGpu * 256);
+        for (int b = 0; b < 2; ++b) {
+            rank->left[b] = devAlloc<uint8_t>(share);
+            rank->right[b] = devAlloc<uint8_t>(share);
+            rank->planes[b] = devAlloc<uint8_t>(share);
+            rank->disparity[b] = devAlloc<int16_t>(share);
+            rank->derivative[b] = devAlloc<int16_t>(share);
+            rank->hist[b] = devAlloc<int32_t>((size_t)framesPerGpu * 256);
+            if (r == 0 && n > 1) {
+                rank->stageLeft[b] = devAlloc<uint8_t>(share * n);
+                rank->stageRight[b] = devAlloc<uint8_t>(share * n);
+                rank->stagePlanes[b] = devAlloc<uint8_t>(share * n);
+                rank->stageDisparity[b] = devAlloc<int16_t>(share * n);
+            }
+            for (hipEvent_t *e : {&rank->scattered[b], &rank->computed[b], &rank->gathered[b]})
+                hipOk(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+        }
+        hipOk(hipEventCreateWithFlags(&rank->inputsReady, hipEventDisableTiming), "hipEventCreate");
         rank->histByRank = devAlloc<int32_t>((size_t)n * framesPerGpu * 256);
         rank->histById = devAlloc<int32_t>((size_t)n * framesPerGpu * 256);
         rank->paramsAll = devAlloc<cart_plane_params>((size_t)n * framesPerGpu);
@@ -83,77 +131,172 @@ FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params p
 
 FrameSharder::~FrameSharder() = default;
 
-void FrameSharder::processSequence(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes) {
+void FrameSharder::submit(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes, void *callerStream) {
     const int n = gpus();
     if (!left || !right || !disparity || !planes) throw std::invalid_argument("NULL image pointer");
-    if (nFrames < 1 || nFrames % n || nFrames > capacity())
-        throw std::invalid_argument("sequence length " + std::to_string(nFrames) + " is not a positive multiple of the " + std::to_string(n) +
-                                    " GPUs within the capacity of " + std::to_string(capacity()) + " frames");
-    const int local = nFrames / n;
-    const size_t npx = (size_t)width * height;
+    if (nFrames < 1 || nFrames > capacity())
+        throw std::invalid_argument("sequence length " + std::to_string(nFrames) + " is outside [1, " + std::to_string(capacity()) + "] (frames per GPU x GPUs)");
+    const size_t npx = (size_t)width * height, share = (size_t)framesPerGpu * npx;
+    const int b = (int)(submitted & 1);
+    const int nMax = shareOf(nFrames, 0, n);   // the longest share: what the all-gather moves per GPU
     Rank &root = *ranks[0];
+    hipOk(hipSetDevice(root.device), "hipSetDevice");
+    if (submitted >= 2) hipOk(hipEventSynchronize(root.gathered[b]), "hipEventSynchronize");   // at most two sequences in flight
 
-    // ---- scatter: frame k -> GPU k mod n, local index k / n.  One group: every send has its receive posted with it.
-    ncclOk(ncclGroupStart(), "ncclGroupStart");
-    for (int r = 0; r < n; ++r)
-        for (int j = 0; j < local; ++j) {
-            const size_t k = (size_t)j * n + r;
-            ncclOk(ncclSend(left + k * npx, npx, ncclUint8, r, root.comm, root.stream), "ncclSend");
-            ncclOk(ncclRecv(ranks[r]->left + (size_t)j * npx, npx, ncclUint8, 0, ranks[r]->comm, ranks[r]->stream), "ncclRecv");
-            ncclOk(ncclSend(right + k * npx, npx, ncclUint8, r, root.comm, root.stream), "ncclSend");
-            ncclOk(ncclRecv(ranks[r]->right + (size_t)j * npx, npx, ncclUint8, 0, ranks[r]->comm, ranks[r]->stream), "ncclRecv");
+    // ---- scatter on the copy streams: frame k -> GPU k mod n, local index k / n.  GPU 0 packs every peer's frames (every n-th
+    //      of the sequence) into one contiguous area, so a peer gets ONE send per image kind; its own share is a local copy.
+    hipOk(hipEventRecord(root.inputsReady, static_cast<hipStream_t>(callerStream)), "hipEventRecord");
+    hipOk(hipStreamWaitEvent(root.copy, root.inputsReady, 0), "hipStreamWaitEvent");
+    for (int r = 0; r < n; ++r) {
+        const int local = shareOf(nFrames, r, n);
+        if (!local) continue;
+        uint8_t *dl = r == 0 ? root.left[b] : root.stageLeft[b] + r * share, *dr = r == 0 ? root.right[b] : root.stageRight[b] + r * share;
+        hipOk(hipMemcpy2DAsync(dl, npx, left + (size_t)r * npx, (size_t)n * npx, npx, local, hipMemcpyDeviceToDevice, root.copy), "hipMemcpy2DAsync");
+        hipOk(hipMemcpy2DAsync(dr, npx, right + (size_t)r * npx, (size_t)n * npx, npx, local, hipMemcpyDeviceToDevice, root.copy), "hipMemcpy2DAsync");
+    }
+    {
+        NcclGroup group;   // every send has its receive posted with it
+        for (int r = 1; r < n; ++r) {
+            const size_t count = (size_t)shareOf(nFrames, r, n) * npx;
+            if (!count) continue;
+            ncclOk(ncclSend(root.stageLeft[b] + r * share, count, ncclUint8, r, root.commCopy, root.copy), "ncclSend");
+            ncclOk(ncclRecv(ranks[r]->left[b], count, ncclUint8, 0, ranks[r]->commCopy, ranks[r]->copy), "ncclRecv");
+            ncclOk(ncclSend(root.stageRight[b] + r * share, count, ncclUint8, r, root.commCopy, root.copy), "ncclSend");
+            ncclOk(ncclRecv(ranks[r]->right[b], count, ncclUint8, 0, ranks[r]->commCopy, ranks[r]->copy), "ncclRecv");
         }
-    ncclOk(ncclGroupEnd(), "ncclGroupEnd");
-
-    // ---- every GPU: disparity and plane derivative + per-frame histograms of its share
+        group.end();
+    }
     for (auto &rk : ranks) {
         hipOk(hipSetDevice(rk->device), "hipSetDevice");
-        cartOk(cart_compute_disparity_batch(rk->engine, local, rk->left, (size_t)width, npx, rk->right, (size_t)width, npx, 1, rk->disparity, (size_t)width * 2,
-                                            npx * 2, rk->stream),
-               rk->engine, "cart_compute_disparity_batch");
-        hipOk(hipMemsetAsync(rk->hist, 0, (size_t)local * 256 * sizeof(int32_t), rk->stream), "hipMemsetAsync");
-        cartOk(cart_plane_derivative_hist(rk->engine, local, rk->disparity, (size_t)width * 2, npx * 2, rk->derivative, (size_t)width * 2, npx * 2, rk->hist, 256,
-                                          rk->stream),
-               rk->engine, "cart_plane_derivative_hist");
+        hipOk(hipEventRecord(rk->scattered[b], rk->copy), "hipEventRecord");
+    }
+
+    // ---- the previous sequence's gather goes onto the copy streams BEHIND this scatter: the scatter is not held up by the wait
+    //      for that sequence's kernels, and the gather runs beside the kernels enqueued below
+    if (pending.live) {
+        postGather(pending);
+        pending.live = false;
+    }
+
+    // ---- every GPU: disparity and plane derivative + per-frame histograms of its share
+    for (int r = 0; r < n; ++r) {
+        Rank &rk = *ranks[r];
+        const int local = shareOf(nFrames, r, n);
+        hipOk(hipSetDevice(rk.device), "hipSetDevice");
+        hipOk(hipStreamWaitEvent(rk.compute, rk.scattered[b], 0), "hipStreamWaitEvent");
+        if (submitted >= 2) hipOk(hipStreamWaitEvent(rk.compute, rk.gathered[b], 0), "hipStreamWaitEvent");   // the outputs of sequence i-2 have left this buffer set
+        hipOk(hipMemsetAsync(rk.hist[b], 0, (size_t)nMax * 256 * sizeof(int32_t), rk.compute), "hipMemsetAsync");   // short shares travel zero-padded
+        if (!local) continue;
+        cartOk(cart_compute_disparity_batch(rk.engine, local, rk.left[b], (size_t)width, npx, rk.right[b], (size_t)width, npx, 1, rk.disparity[b],
+                                            (size_t)width * 2, npx * 2, rk.compute),
+               rk.engine, "cart_compute_disparity_batch");
+        cartOk(cart_plane_derivative_hist(rk.engine, local, rk.disparity[b], (size_t)width * 2, npx * 2, rk.derivative[b], (size_t)width * 2, npx * 2,
+                                          rk.hist[b], 256, rk.compute),
+               rk.engine, "cart_plane_derivative_hist");
     }
 
     // ---- the path's only exchange step: all-gather of the per-frame histograms (1 KB per frame)
-    ncclOk(ncclGroupStart(), "ncclGroupStart");
-    for (auto &rk : ranks) ncclOk(ncclAllGather(rk->hist, rk->histByRank, (size_t)local * 256, ncclInt32, rk->comm, rk->stream), "ncclAllGather");
-    ncclOk(ncclGroupEnd(), "ncclGroupEnd");
+    {
+        NcclGroup group;
+        for (auto &rk : ranks)
+            ncclOk(ncclAllGather(rk->hist[b], rk->histByRank, (size_t)nMax * 256, ncclInt32, rk->commCompute, rk->compute), "ncclAllGather");
+        group.end();
+    }
 
-    // ---- every GPU: histograms into frame-id order ([rank][j] -> j * n + rank), schedule replay for the whole sequence,
-    //      its own frames' parameters (every n-th row), classification
+    // ---- every GPU: histograms into frame-id order ([rank][j] -> j * n + rank; the padded rows are exactly the ids >= nFrames),
+    //      schedule replay for the whole sequence, its own frames' parameters (every n-th row), classification
     for (int r = 0; r < n; ++r) {
         Rank &rk = *ranks[r];
+        const int local = shareOf(nFrames, r, n);
         hipOk(hipSetDevice(rk.device), "hipSetDevice");
         for (int src = 0; src < n; ++src)
-            hipOk(hipMemcpy2DAsync(rk.histById + (size_t)src * 256, (size_t)n * 1024, rk.histByRank + (size_t)src * local * 256, 1024, 1024, local,
-                                   hipMemcpyDeviceToDevice, rk.stream),
+            hipOk(hipMemcpy2DAsync(rk.histById + (size_t)src * 256, (size_t)n * 1024, rk.histByRank + (size_t)src * nMax * 256, 1024, 1024, nMax,
+                                   hipMemcpyDeviceToDevice, rk.compute),
                   "hipMemcpy2DAsync");
-        cartOk(cart_plane_schedule_advance(rk.schedule, nextId, nFrames, rk.histById, rk.paramsAll, rk.stream), rk.engine, "cart_plane_schedule_advance");
-        hipOk(hipMemcpy2DAsync(rk.paramsMine, sizeof(cart_plane_params), rk.paramsAll + r, (size_t)n * sizeof(cart_plane_params), sizeof(cart_plane_params), local,
-                               hipMemcpyDeviceToDevice, rk.stream),
-              "hipMemcpy2DAsync");
-        cartOk(cart_plane_classify_dev(rk.engine, local, rk.derivative, (size_t)width * 2, npx * 2, rk.paramsMine, 1, rk.planes, (size_t)width, npx, rk.stream),
-               rk.engine, "cart_plane_classify_dev");
-    }
-
-    // ---- gather: outputs back to GPU 0 in sequence order (RCCL has no 16-bit integer type: disparities travel as bytes)
-    ncclOk(ncclGroupStart(), "ncclGroupStart");
-    for (int r = 0; r < n; ++r)
-        for (int j = 0; j < local; ++j) {
-            const size_t k = (size_t)j * n + r;
-            ncclOk(ncclSend(ranks[r]->disparity + (size_t)j * npx, npx * 2, ncclUint8, 0, ranks[r]->comm, ranks[r]->stream), "ncclSend");
-            ncclOk(ncclRecv(disparity + k * npx, npx * 2, ncclUint8, r, root.comm, root.stream), "ncclRecv");
-            ncclOk(ncclSend(ranks[r]->planes + (size_t)j * npx, npx, ncclUint8, 0, ranks[r]->comm, ranks[r]->stream), "ncclSend");
-            ncclOk(ncclRecv(planes + k * npx, npx, ncclUint8, r, root.comm, root.stream), "ncclRecv");
+        cartOk(cart_plane_schedule_advance(rk.schedule, nextId, nFrames, rk.histById, rk.paramsAll, rk.compute), rk.engine, "cart_plane_schedule_advance");
+        if (local) {
+            hipOk(hipMemcpy2DAsync(rk.paramsMine, sizeof(cart_plane_params), rk.paramsAll + r, (size_t)n * sizeof(cart_plane_params), sizeof(cart_plane_params),
+                                   local, hipMemcpyDeviceToDevice, rk.compute),
+                  "hipMemcpy2DAsync");
+            cartOk(cart_plane_classify_dev(rk.engine, local, rk.derivative[b], (size_t)width * 2, npx * 2, rk.paramsMine, 1, rk.planes[b], (size_t)width, npx,
+                                           rk.compute),
+                   rk.engine, "cart_plane_classify_dev");
         }
-    ncclOk(ncclGroupEnd(), "ncclGroupEnd");
+        hipOk(hipEventRecord(rk.computed[b], rk.compute), "hipEventRecord");
+    }
+    pending = Pending{nFrames, disparity, planes, b, true};
+    nextId += nFrames;
+    ++submitted;
+}
+
+// outputs back to GPU 0 in sequence order (RCCL has no 16-bit integer type: disparities travel as bytes)
+void FrameSharder::postGather(const Pending &p) {
+    const int n = gpus(), b = p.buf;
+    const size_t npx = (size_t)width * height, share = (size_t)framesPerGpu * npx;
+    Rank &root = *ranks[0];
     for (auto &rk : ranks) {
         hipOk(hipSetDevice(rk->device), "hipSetDevice");
-        hipOk(hipStreamSynchronize(rk->stream), "hipStreamSynchronize");
+        hipOk(hipStreamWaitEvent(rk->copy, rk->computed[b], 0), "hipStreamWaitEvent");
     }
-    nextId += nFrames;
+    {
+        NcclGroup group;
+        for (int r = 1; r < n; ++r) {
+            const size_t count = (size_t)shareOf(p.nFrames, r, n) * npx;
+            if (!count) continue;
+            ncclOk(ncclSend(ranks[r]->disparity[b], count * 2, ncclUint8, 0, ranks[r]->commCopy, ranks[r]->copy), "ncclSend");
+            ncclOk(ncclRecv(root.stageDisparity[b] + r * share, count * 2, ncclUint8, r, root.commCopy, root.copy), "ncclRecv");
+            ncclOk(ncclSend(ranks[r]->planes[b], count, ncclUint8, 0, ranks[r]->commCopy, ranks[r]->copy), "ncclSend");
+            ncclOk(ncclRecv(root.stagePlanes[b] + r * share, count, ncclUint8, r, root.commCopy, root.copy), "ncclRecv");
+        }
+        group.end();
+    }
+    hipOk(hipSetDevice(root.device), "hipSetDevice");
+    for (int r = 0; r < n; ++r) {   // share of GPU r -> every n-th frame of the caller's arrays
+        const int local = shareOf(p.nFrames, r, n);
+        if (!local) continue;
+        const int16_t *sd = r == 0 ? root.disparity[b] : root.stageDisparity[b] + r * share;
+        const uint8_t *sp = r == 0 ? root.planes[b] : root.stagePlanes[b] + r * share;
+        hipOk(hipMemcpy2DAsync(p.disparity + (size_t)r * npx, (size_t)n * npx * 2, sd, npx * 2, npx * 2, local, hipMemcpyDeviceToDevice, root.copy), "hipMemcpy2DAsync");
+        hipOk(hipMemcpy2DAsync(p.planes + (size_t)r * npx, (size_t)n * npx, sp, npx, npx, local, hipMemcpyDeviceToDevice, root.copy), "hipMemcpy2DAsync");
+    }
+    for (auto &rk : ranks) {
+        hipOk(hipSetDevice(rk->device), "hipSetDevice");
+        hipOk(hipEventRecord(rk->gathered[b], rk->copy), "hipEventRecord");
+    }
+}
+
+void FrameSharder::wait(double timeoutSeconds) {
+    if (pending.live) {
+        postGather(pending);
+        pending.live = false;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeoutSeconds);
+    for (int r = 0; r < gpus(); ++r) {
+        Rank &rk = *ranks[r];
+        hipOk(hipSetDevice(rk.device), "hipSetDevice");
+        for (hipStream_t s : {rk.compute, rk.copy}) {
+            for (;;) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) throw std::runtime_error("GPU " + std::to_string(rk.device) + " (rank " + std::to_string(r) + "): " + hipGetErrorString(q));
+                if (std::chrono::steady_clock::now() > deadline) {
+                    // which collective is stuck: the asynchronous error state of this GPU's two communicators
+                    ncclResult_t ec = ncclSuccess, ex = ncclSuccess;
+                    (void)ncclCommGetAsyncError(rk.commCompute, &ec);
+                    (void)ncclCommGetAsyncError(rk.commCopy, &ex);
+                    throw std::runtime_error("GPU " + std::to_string(rk.device) + " (rank " + std::to_string(r) + ") did not finish its " +
+                                             (s == rk.compute ? "kernels / histogram all-gather" : "scatter / gather") + " within " +
+                                             std::to_string(timeoutSeconds) + " s; RCCL state: all-gather communicator " + ncclGetErrorString(ec) +
+                                             ", scatter/gather communicator " + ncclGetErrorString(ex));
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    }
+}
+
+void FrameSharder::processSequence(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes) {
+    submit(left, right, nFrames, disparity, planes);
+    wait();
 }
 }  // namespace cart

@@ -68,13 +68,17 @@ void cart_engine_destroy(cart_engine *engine);
 
 /* Launch plans of the SGM core.  Every plan produces the same bits; they differ in which path slabs exist in HBM.
  *   SLABS     all P path slabs are written by the aggregation launch and read by the WTA launch (2*P*D bytes / pixel);
- *   FUSED_UP  the "up" path is computed inside the WTA sweep and never stored (2*(P-1)*D bytes / pixel);
+ *   FUSED_UP  the "up" path is computed inside the WTA sweep and never stored (2*(P-1)*D bytes / pixel).
+ * AUTO picks per launch from the measured table in DESIGN.md section 4.  Options are plain integers so that the
+ * boundary stays C; nothing in the engine reads the environment.
+ *
+ * EXPERIMENTAL, measured and lost (kept as a tested, bit-exact option because it is the measurement
+ * that closed the question -- AUTO never picks it and no module adapter uses it):
  *   PAIRS     (8 paths) {down, down-right} and {up, up-right} each ride on one sweep over the image rows and leave ONE u8
  *             slab holding the sum of their penalty parts: 6 slabs instead of 8 (2*6*D bytes / pixel); the WTA adds the
- *             shared 4*C back from the census planes.  Needs 2*p2 <= 255; other engines fall back to FUSED_UP.
- *             Measured slower than SLABS on MI355X: an option, never picked by AUTO.
- * AUTO picks per launch from the measured table in DESIGN.md section 4.  Options are plain integers so that the
- * boundary stays C; nothing in the engine reads the environment. */
+ *             shared 4*C back from the census planes.  Needs 2*p2 <= 255 and w*h*D < ~2^30 (32-bit lane offsets of the
+ *             sweep's sink slab); other engines fall back to FUSED_UP.  3.9-4.1 ms per 16 pairs at 16, 32 and 48 frames per
+ *             launch against 3.0 for SLABS (profiles/r03_stageA.txt). */
 enum { CART_PLAN_AUTO = -1, CART_PLAN_SLABS = 0, CART_PLAN_FUSED_UP = 1, CART_PLAN_PAIRS = 2 };
 enum {
     CART_OPT_PLAN = 0,            /* CART_PLAN_*; default AUTO */
@@ -92,10 +96,12 @@ typedef struct {
 } cart_launch_plan;
 int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_plan *out);
 
-/* Synchronises the device and returns the engine's device status word: 0 = healthy.  Bit 0: a pair sweep (plan PAIRS)
- * gave up waiting for the hand-over of its left neighbour block (bounded poll, so that a grid always drains); the
- * disparities of that call are then invalid.  It cannot happen on a healthy device; callers that want to know (tests,
- * the module adapter after its stream synchronise) ask here. */
+/* Synchronises the device, returns the engine's device status word and CLEARS it (0 = healthy), so a report covers the
+ * calls made since the previous query.  Bit 0: a pair sweep (plan PAIRS) gave up waiting for the hand-over of its left
+ * neighbour block (bounded poll, so that a grid always drains); the disparities of those calls are then invalid.  It
+ * cannot happen on a healthy device and only a caller that forces CART_PLAN_PAIRS can see it: such a caller asks here
+ * after its stream synchronise (the Python driver's Engine.device_status(); the soak tool and the PAIRS tests do).  The
+ * module adapters never force a plan and need not ask. */
 int cart_engine_device_status(cart_engine *engine, unsigned *status);
 
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
@@ -117,34 +123,6 @@ int cart_compute_disparity_batch(cart_engine *engine, int n_frames,
                                  const uint8_t *right, size_t right_step, size_t right_frame_stride,
                                  int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
                                  void *stream);
-
-/* cart_compute_disparity_batch + a gate for a second stream of the caller: `gated_stream` is made to wait (hipStreamWaitEvent)
- * for the point of `stream` where this call's path aggregation has finished and its WTA is about to start.  Work the caller
- * enqueues on `gated_stream` afterwards therefore runs beside the HBM-bound WTA / post stages of this batch instead of beside
- * its aggregation, whose W-step horizontal scans are slowed by any neighbour (the batched driver puts the previous batch's
- * plane stages there: cartslam/pipeline.py, overlap="deferred").  No reference counterpart (the reference runs one frame per
- * stream, disparity.cu:56).  gated_stream == NULL or == stream: plain cart_compute_disparity_batch. */
-int cart_compute_disparity_batch_gated(cart_engine *engine, int n_frames,
-                                       const uint8_t *left, size_t left_step, size_t left_frame_stride,
-                                       const uint8_t *right, size_t right_step, size_t right_frame_stride,
-                                       int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
-                                       void *stream, void *gated_stream);
-
-/* cart_compute_disparity_batch with its stages spread over up to three streams of the caller (NULL = `stream`):
- *   census_stream  the gray conversion + census transform run there; the caller guarantees that the input images are
- *                  complete on that stream (e.g. it has made it wait for the upload).  `stream` waits for the census.
- *   tail_stream    everything after the WTA (medians, LR check, range fix, interpolate) runs there, after a wait for the
- *                  WTA; `out` is then produced on tail_stream, and what the caller enqueues there afterwards sees it.
- *   gated_stream   as in cart_compute_disparity_batch_gated.
- * `stream` itself then carries only the two long launches (path aggregation, WTA), back to back from batch to batch; the
- * short VALU-bound census of the next batch runs beside the HBM-bound WTA of this one.  An option for callers whose inputs
- * arrive on a copy stream; on resident batches it measured +1-4 % at D=64 / 4 paths and -1-3 % elsewhere.
- * The reference has one stream per frame (disparity.cu:56) and no counterpart; its adapter uses the plain call. */
-int cart_compute_disparity_batch_streams(cart_engine *engine, int n_frames,
-                                         const uint8_t *left, size_t left_step, size_t left_frame_stride,
-                                         const uint8_t *right, size_t right_step, size_t right_frame_stride,
-                                         int channels, int16_t *out, size_t out_step, size_t out_frame_stride,
-                                         void *stream, void *census_stream, void *tail_stream, void *gated_stream);
 
 /* The same for frames that live in separate allocations: left[f] / right[f] / out[f] are the device images of frame f
  * (host arrays of n_frames device pointers, read before the call returns; one step per image kind).  This is what a

@@ -3,7 +3,7 @@
   python dist_worker.py <rank> <world> <port> <out.npz> <w> <h> <D> <P> <n_local> <steps> <ui> <ri> <device_schedule>
 
 Every rank drives the REAL engine through StereoPipeline (process_batch for `steps` steps, then one process_sequence whose
-frames start on rank 0) with the gloo backend, all ranks on cuda:0 -- the frame sharding, the histogram all-gather, the
+frames start on rank 0, then three pipelined submit_sequence calls, one of uneven length) with the gloo backend, all ranks on cuda:0 -- the frame sharding, the histogram all-gather, the
 permute to id order, the device / host plane-parameter schedule and the scatter/gather of the sequence mode are the
 product code of cartslam/pipeline.py; only the transport differs from RCCL."""
 import os
@@ -66,6 +66,25 @@ def main():
             res["seq_planes"] = got["planes"].cpu().numpy()
         else:
             assert got["disparity"] is None and got["planes"] is None
+        next_id += n_seq
+        # pipelined sequence mode: three sequences submitted back to back (the middle one one frame longer: the first rank
+        # then holds one frame more), results asked for afterwards
+        lengths = [n_seq, n_seq + 1, n_seq]
+        handles = []
+        for n in lengths:
+            sl = sr = None
+            if rank == 0:
+                ls, rs = frames_of(range(next_id, next_id + n), w, h, D, 4321)
+                sl, sr = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
+            handles.append(pipe.submit_sequence(sl, sr, n))
+            next_id += n
+        for k, hd in enumerate(handles):
+            got = hd.result()
+            if rank == 0:
+                res[f"pseq{k}_disp"] = got["disparity"].cpu().numpy()
+                res[f"pseq{k}_planes"] = got["planes"].cpu().numpy()
+            else:
+                assert got["disparity"] is None and got["planes"] is None
         np.savez(out_path, **res)
         eng.close()
     finally:

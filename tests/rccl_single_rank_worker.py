@@ -28,7 +28,7 @@ def main():
     try:
         assert dist.get_backend() == "nccl"
         w, h, D, P, n, ui, ri = 256, 96, 64, 8, 6, 4, 2
-        eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n)
+        eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=4 * n)
         res = {}
         for dev_sched in (True, False):
             pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True,
@@ -44,6 +44,16 @@ def main():
             torch.cuda.synchronize()
             res[f"disp_{int(dev_sched)}_2"] = got["disparity"].cpu().numpy()
             res[f"planes_{int(dev_sched)}_2"] = got["planes"].cpu().numpy()
+            # pipelined: three sequences submitted back to back (scatter of i+1 and gather of i-1 on the copy stream beside
+            # the kernels of i, all through RCCL), results asked for afterwards
+            handles = []
+            for s in range(3, 6):
+                ls, rs = frames_of(range(s * n + 1, (s + 1) * n + 1), w, h, D, 4321)
+                handles.append(pipe.submit_sequence(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda(), n))
+            for s, hd in zip(range(3, 6), handles):
+                got = hd.result()
+                res[f"disp_{int(dev_sched)}_{s}"] = got["disparity"].cpu().numpy()
+                res[f"planes_{int(dev_sched)}_{s}"] = got["planes"].cpu().numpy()
         t = torch.ones(4, device="cuda")
         dist.all_reduce(t)   # what bench.py does with its elapsed time
         dist.barrier()

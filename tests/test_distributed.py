@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_lib as O
-from cartslam.pipeline import PlaneParameterSchedule, gather_sequence, scatter_sequence, shard_ids
+from cartslam.pipeline import CollectiveError, PlaneParameterSchedule, SequencePipeliner, gather_sequence, scatter_sequence, share_of, shard_ids
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -114,19 +114,40 @@ def test_world_size_2_gloo_equals_single_process():
         assert params == exp[fid - 1], f"frame {fid}"
 
 
+def _spawn(target, world, args, timeout=90, expect_exit=None):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    for _ in range(world if expect_exit is None else sum(1 for e in expect_exit if e is not None)):
+        results.append(q.get(timeout=timeout))
+    for r, p in enumerate(procs):
+        p.join(timeout=timeout)
+        if expect_exit is None:
+            assert p.exitcode == 0, f"rank {r} exited with {p.exitcode}"
+    return results, [p.exitcode for p in procs]
+
+
+def _frames(n_total, h=6, w=10, salt=0):
+    return ((torch.arange(n_total * h * w, dtype=torch.int32) * 7 + salt) % 251).reshape(n_total, h, w).to(torch.uint8)
+
+
 def _sequence_worker(rank, world, port, n_total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         h, w = 6, 10
-        seq = torch.arange(n_total * h * w, dtype=torch.int32).reshape(n_total, h, w).to(torch.uint8) if rank == 0 else None
+        full = _frames(n_total, h, w)
+        seq = full.clone() if rank == 0 else None
         mine = scatter_sequence(seq, n_total, ((h, w), torch.uint8, "cpu"), root=0)
-        ids = shard_ids(1, n_total // world, rank, world)   # frame k (id k + 1) -> rank k mod world
-        full = torch.arange(n_total * h * w, dtype=torch.int32).reshape(n_total, h, w).to(torch.uint8)
-        ok_scatter = all(torch.equal(mine[j], full[i - 1]) for j, i in enumerate(ids))
+        n_mine = share_of(n_total, rank, world)
+        ids = shard_ids(1, n_mine, rank, world)   # frame k (id k + 1) -> rank k mod world
+        ok_scatter = mine.shape[0] == n_mine and all(torch.equal(mine[j], full[i - 1]) for j, i in enumerate(ids))
         out = (mine.to(torch.int16) * 3 + rank)   # stands in for this rank's outputs
-        back = gather_sequence(out, root=0)
-        ok_gather = True
+        back = gather_sequence(out, n_total, root=0)
         if rank == 0:
             want = full.to(torch.int16) * 3 + (torch.arange(n_total) % world).to(torch.int16)[:, None, None]
             ok_gather = torch.equal(back, want)
@@ -134,7 +155,7 @@ def _sequence_worker(rank, world, port, n_total, q):
             ok_gather = back is None
         bad = None
         try:
-            scatter_sequence(None, n_total + 1, ((h, w), torch.uint8, "cpu"))
+            gather_sequence(out[:0] if n_mine else torch.zeros((1, h, w), dtype=torch.int16), n_total, root=0)   # a share of the wrong length
         except ValueError as e:
             bad = str(e)
         q.put((rank, ok_scatter, ok_gather, bad))
@@ -142,20 +163,88 @@ def _sequence_worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-def test_sequence_scatter_gather_world_2():
+@pytest.mark.parametrize("n_total", [8, 7, 1])
+def test_sequence_scatter_gather_world_2(n_total):
     """BASELINE configs[4] plumbing: a sequence on rank 0 is dealt out frame k -> rank k mod world and the outputs come
-    back in sequence order; a length that does not divide is refused on every rank before any collective is posted."""
-    world, n_total = 2, 8
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sequence_worker, args=(r, world, port, n_total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=60) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    back in sequence order.  A length that does not divide gives the first ranks one frame more (7 -> 4 + 3), a sequence
+    shorter than the world leaves a rank with nothing to compute (1 -> 1 + 0); a share of the wrong length is refused
+    before any collective is posted."""
+    results, _ = _spawn(_sequence_worker, 2, (n_total,))
     for rank, ok_scatter, ok_gather, bad in results:
         assert ok_scatter and ok_gather, rank
-        assert bad and "multiple of the world size" in bad
+        assert bad and "frames of a" in bad
+
+
+def _fake_compute(rank):
+    # stands in for StereoPipeline.process_batch: outputs that depend on both inputs, the rank and a per-call counter
+    # (a pipeline that handed a later sequence's frames to an earlier handle would be caught by the counter)
+    state = {"calls": 0}
+    def compute(l, r, n_total):
+        state["calls"] += 1
+        return {"disparity": l.to(torch.int16) * 2 - r.to(torch.int16) + 100 * state["calls"],
+                "planes": ((l.to(torch.int32) + r.to(torch.int32) + rank) % 3).to(torch.uint8)}
+    return compute
+
+
+def _pipeliner_worker(rank, world, port, lengths, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        h, w = 6, 10
+        seqs = [(_frames(n, h, w, 3 * i), _frames(n, h, w, 3 * i + 1)) for i, n in enumerate(lengths)]
+        got = {}
+        for mode in ("serial", "pipelined"):
+            sp = SequencePipeliner(_fake_compute(rank), (h, w), device="cpu")
+            give = lambda i: (seqs[i][0].clone(), seqs[i][1].clone()) if rank == 0 else (None, None)
+            if mode == "serial":
+                outs = [sp.submit(*give(i), lengths[i]).result() for i in range(len(lengths))]
+            else:
+                hs = [sp.submit(*give(i), lengths[i]) for i in range(len(lengths))]   # all submitted before any result is asked for
+                outs = [hd.result() for hd in hs]
+            got[mode] = outs
+        ok = True
+        if rank == 0:
+            for i, n in enumerate(lengths):
+                l, r = seqs[i]
+                who = (torch.arange(n) % world)[:, None, None]
+                want_d = l.to(torch.int16) * 2 - r.to(torch.int16) + 100 * (i + 1)
+                want_p = ((l.to(torch.int32) + r.to(torch.int32) + who) % 3).to(torch.uint8)
+                for mode in got:
+                    ok &= torch.equal(got[mode][i]["disparity"], want_d) and torch.equal(got[mode][i]["planes"], want_p)
+        else:
+            ok = all(o["disparity"] is None and o["planes"] is None for outs in got.values() for o in outs)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_sequences_equal_one_at_a_time_world_2():
+    """SequencePipeliner over gloo, two ranks: four back-to-back sequences (even, odd, shorter than the world, even) give the
+    same gathered outputs whether each is waited for before the next is submitted or all are submitted first -- the order in
+    which scatter(i+1) and gather(i) are posted is the same on both ranks, so no collective can pair with the wrong one."""
+    results, _ = _spawn(_pipeliner_worker, 2, ((8, 7, 1, 6),))
+    assert sorted(r for r, _ in results) == [0, 1] and all(ok for _, ok in results)
+
+
+def _dead_peer_worker(rank, world, port, q):
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=5))
+    if rank == 1:
+        os._exit(0)   # the peer dies without joining the exchange
+    try:
+        scatter_sequence(_frames(4), 4, ((6, 10), torch.uint8, "cpu"), root=0)
+        q.put((rank, "no error"))
+    except CollectiveError as e:
+        q.put((rank, str(e)))
+        q.close(); q.join_thread()   # the message has left this process before it goes away
+        os._exit(3)   # what bench.py does: a non-zero exit that names the rank, no teardown that waits for the dead peer
+
+
+def test_dead_peer_ends_the_job_with_the_rank_named():
+    """A collective whose peer is gone must not hang: the process group's timeout turns it into a CollectiveError that
+    names the rank and the call, and the process exits non-zero."""
+    results, codes = _spawn(_dead_peer_worker, 2, (), timeout=60, expect_exit=[3, None])
+    (rank, msg), = results
+    assert rank == 0 and "rank 0" in msg and "scatter(sequence)" in msg, msg
+    assert codes[0] == 3

@@ -901,10 +901,10 @@ def test_resize_linear(torch_cuda, sw, sh, dw, dh, ch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [4, 8])
-def test_deferred_overlap_gives_the_same_outputs(torch_cuda, P):
-    """StereoPipeline(overlap="deferred") -- the plane stages of batch i enqueued by the next call, on the side stream, gated
-    behind the aggregation of batch i+1 (cart_compute_disparity_batch_gated) -- returns, one call later, exactly what the
-    one-stream pipeline returns: five batches whose scenes differ, a parameter refresh in between (ids 1 and 31)."""
+def test_side_stream_overlap_gives_the_same_outputs(torch_cuda, P):
+    """StereoPipeline(overlap=True) -- the plane stages of batch i on a side stream beside the disparity kernels of batch
+    i+1, with and without the caller's inputs-ready event -- returns exactly what the one-stream pipeline returns: five
+    batches whose scenes differ, a parameter refresh in between (ids 1 and 31)."""
     torch = torch_cuda
     from cartslam.pipeline import StereoPipeline
     w, h, D, B = 330, 120, 64, 8
@@ -915,68 +915,48 @@ def test_deferred_overlap_gives_the_same_outputs(torch_cuda, P):
     results = {}
     torch.cuda.synchronize()
     ready = torch.cuda.current_stream().record_event()   # the inputs are complete from here on
-    # "split": post stages on the side stream; "split_ready": the census on a third stream as well (the inputs' event given)
-    for mode in (False, "deferred", "split", "split_ready"):
+    for mode in ("one_stream", "side", "side_ready"):
         eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2 * B)
-        pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=True if str(mode).startswith("split") else mode,
-                              split_stages=str(mode).startswith("split"))
-        assert pipe.split_stages == str(mode).startswith("split")
-        outs = []
-        for l, r in batches:
-            o = pipe.process_batch(l, r, inputs_ready=ready if mode == "split_ready" else None)
-            if o is not None:
-                outs.append(o)
-        last = pipe.flush()
-        assert (last is None) == (mode != "deferred")
-        if last is not None:
-            outs.append(last)
+        pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=mode != "one_stream")
+        assert (pipe.side is not None) == (mode != "one_stream")
+        outs = [pipe.process_batch(l, r, inputs_ready=ready if mode == "side_ready" else None) for l, r in batches]
         torch.cuda.synchronize()
-        assert len(outs) == len(batches)
         results[mode] = [{k: o[k].cpu().numpy() for k in ("disparity", "planes", "ids", "n_components", "components", "params")} for o in outs]
         eng.close()
-    for mode in ("deferred", "split", "split_ready"):
-      for a, b in zip(results[False], results[mode]):
-        for k in a:
-            if k == "components":   # rows past a frame's component count are not written
-                for f in range(B):
-                    nc = min(int(a["n_components"][f]), a[k].shape[1])
-                    assert np.array_equal(a[k][f, :nc], b[k][f, :nc]), (mode, k, f)
-            else:
-                assert np.array_equal(a[k], b[k]), (mode, k)
+    for mode in ("side", "side_ready"):
+        for a, b in zip(results["one_stream"], results[mode]):
+            for k in a:
+                if k == "components":   # rows past a frame's component count are not written
+                    for f in range(B):
+                        nc = min(int(a["n_components"][f]), a[k].shape[1])
+                        assert np.array_equal(a[k][f, :nc], b[k][f, :nc]), (mode, k, f)
+                else:
+                    assert np.array_equal(a[k], b[k]), (mode, k)
     # the frames really differ from batch to batch (otherwise a one-batch shift would go unnoticed)
-    assert not np.array_equal(results[False][0]["disparity"], results[False][1]["disparity"])
+    assert not np.array_equal(results["one_stream"][0]["disparity"], results["one_stream"][1]["disparity"])
 
 
 @pytest.mark.gpu
-def test_gated_batch_call(torch_cuda):
-    """cart_compute_disparity_batch_gated: same bits as the plain call; a gated stream equal to the launch stream is the plain call;
-    work enqueued on the gated stream afterwards sees the finished aggregation of that call (it is ordered after it)."""
+def test_pairs_plan_is_refused_where_its_32_bit_sink_offset_would_wrap(torch_cuda):
+    """Plan PAIRS sends the stores of columns >= w to a sink slab through a 32-bit lane offset of up to 4 slabs
+    (sgm_kernels.hip, pair_sweep_kernel).  At 4096x2160 / D=128 a slab is 1.13 GB: the engine must fall back to FUSED_UP
+    there (engine_internal.h pairs_offsets_fit) -- and still give the bits of plan SLABS; at 1242x375 it takes PAIRS."""
     torch = torch_cuda
-    w, h, D, P, n = 200, 64, 64, 8, 4
-    ls, rs = synth.make_batch(n, w, h, D, 4)
-    L, R = dev(torch, ls), dev(torch, rs)
-    eng = make_engine(w, h, D, P, 4, inflight=2 * n)
-    ref = eng.compute_disparity(L, R).cpu().numpy()
-    side = torch.cuda.Stream()
-    got = eng.compute_disparity(L, R, gated_stream=side)
-    with torch.cuda.stream(side):
-        marker = torch.ones(1, device="cuda")   # runs once the gate opens
-    same = eng.compute_disparity(L, R, gated_stream=torch.cuda.current_stream())
-    # cart_compute_disparity_batch_streams: census on a third stream, post stages on a second one, three calls back to back
-    pre, tail = torch.cuda.Stream(), torch.cuda.Stream()
-    torch.cuda.synchronize()
-    spread = []
-    for k in range(3):
-        spread.append(eng.compute_disparity(L if k != 1 else R, R if k != 1 else L, census_stream=pre, tail_stream=tail, gated_stream=side))
-    swapped = eng.compute_disparity(R, L)
-    # several launch sequences inside one call (2 frames each): every one hands over census -> main -> tail through its own markers
-    eng.set_chunk_frames(2)
-    chunked = eng.compute_disparity(L, R, census_stream=pre, tail_stream=tail)
-    eng.set_chunk_frames(16)
-    torch.cuda.synchronize()
-    assert (chunked.cpu().numpy() == ref).all()
-    assert float(marker.item()) == 1.0
-    assert (got.cpu().numpy() == ref).all() and (same.cpu().numpy() == ref).all()
-    assert (spread[0].cpu().numpy() == ref).all() and (spread[2].cpu().numpy() == ref).all()
-    assert (spread[1].cpu().numpy() == swapped.cpu().numpy()).all()
+    small = make_engine(1242, 375, 128, 8, 4, inflight=1, plan="pairs")
+    assert small.describe_plan(1)["plan"] == "pairs"
+    small.close()
+    w, h, D, P = 4096, 2160, 128, 8
+    assert 4 * w * h * D + w * D >= 1 << 32
+    eng = make_engine(w, h, D, P, 4, inflight=1, plan="pairs")
+    lp = eng.describe_plan(1)
+    assert lp["plan"] == "fused_up" and lp["slabs_written"] == P - 1
+    # one pair through the fallback and through SLABS: identical
+    rng = np.random.default_rng(5)
+    l = rng.integers(1, 256, (h, w), dtype=np.uint8)
+    r = np.roll(l, -9, axis=1)
+    a = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+    assert eng.device_status() == 0
+    eng.set_plan("slabs")
+    b = eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy()
+    assert (a == b).all()
     eng.close()

@@ -89,7 +89,8 @@ def _free_port():
 
 @pytest.mark.parametrize("device_schedule", [1, 0])
 def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
-    """tests/dist_worker.py x 2 (gloo, one GPU) vs one process: every frame of every step and of the sequence call."""
+    """tests/dist_worker.py x 2 (gloo, one GPU) vs one process: every frame of every step, of the sequence call and of three
+    pipelined sequences (one of uneven length: rank 0 holds one frame more)."""
     import torch
     from cartslam import Engine
     from cartslam.pipeline import StereoPipeline
@@ -107,13 +108,16 @@ def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
         assert pr.returncode == 0, f"rank {r} failed:\n{out.decode(errors='replace')[-3000:]}"
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     # single process, same frames in id order, same batch boundaries in ids
-    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n_local * world)
+    eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n_local * world + 2)
     pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True, device_schedule=bool(device_schedule))
     n_step = n_local * world
-    total = n_step * (steps + 1)
-    seen = 0
-    for s in range(steps + 1):
-        ids = list(range(s * n_step + 1, (s + 1) * n_step + 1))
+    # the batch boundaries of the ranks' run: `steps` batches, the sequence call, then the three pipelined sequences
+    sizes = [n_step] * (steps + 1) + [n_step, n_step + 1, n_step]
+    total = sum(sizes)
+    seen, first = 0, 1
+    for s, size in enumerate(sizes):
+        ids = list(range(first, first + size))
+        first += size
         ls, rs = frames_of(ids, w, h, D, 4321)
         o = pipe.process_batch(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda())
         torch.cuda.synchronize()
@@ -124,11 +128,16 @@ def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
                 assert (z[f"disp_{fid}"] == d1).all(), f"disparity frame {fid}"
                 assert (z[f"planes_{fid}"] == p1).all(), f"planes frame {fid}"
                 assert (z[f"ids_{fid}"] == o["ids"][k].cpu().numpy()).all() and int(z[f"ncomp_{fid}"]) == int(o["n_components"][k].item()), f"ccl frame {fid}"
-            else:
+            elif s == steps:
                 z = ranks[0]
                 assert int(z["seq_first_id"]) == ids[0]
                 assert (z["seq_disp"][k] == d1).all(), f"sequence disparity frame {fid}"
                 assert (z["seq_planes"][k] == p1).all(), f"sequence planes frame {fid}"
+            else:
+                z, q = ranks[0], s - steps - 1
+                assert z[f"pseq{q}_disp"].shape[0] == size
+                assert (z[f"pseq{q}_disp"][k] == d1).all(), f"pipelined sequence {q} disparity frame {fid}"
+                assert (z[f"pseq{q}_planes"][k] == p1).all(), f"pipelined sequence {q} planes frame {fid}"
             seen += 1
     assert seen == total
     assert "seq_disp" not in ranks[1].files
@@ -153,7 +162,7 @@ def test_rccl_collectives_single_rank(tmp_path):
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * n)
     for dev_sched in (1, 0):
         pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True, device_schedule=bool(dev_sched))
-        for s in range(3):
+        for s in range(6):   # two batches, one sequence, three pipelined sequences in the worker
             ls, rs = frames_of(range(s * n + 1, (s + 1) * n + 1), w, h, D, 4321)
             o = pipe.process_batch(torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda())
             torch.cuda.synchronize()
