@@ -23,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cart-slam_amd"))
 
+_REAL_STDOUT = 1   # file descriptor the JSON line is written to (main() moves descriptor 1 out of librccl's way)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
@@ -178,6 +179,13 @@ def main():
     import torch
     import torch.distributed as dist
     from cartslam.pipeline import CollectiveError
+
+    # rank 0 prints ONE JSON line on stdout and nothing else: librccl writes a version banner straight to file descriptor 1
+    # when a communicator is created, so from here on descriptor 1 points at stderr and the line goes to the saved descriptor
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -490,7 +498,8 @@ def run(args, world, rank, dev_index):
                 out["verification"] = {"frames": check_frames, "of": "the last timed step", "against": "oracle (cpu_baseline child): disparity bit-exact, "
                                        "plane labels bit-exact under the parameters the run used", "mismatches": bad}
         out["verified"] = verified   # None: not checked (multi-rank runs and --no-cpu-baseline have no CPU leg)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
         if verified is False:
             sys.stderr.write("bench.py: the timed configuration's outputs differ from the oracle: " + "; ".join(bad) + "\n")
             if dist.is_initialized():

@@ -5,6 +5,13 @@ above the horizon, a ground plane below it (constant non-zero vertical disparity
 "horizontal plane" histogram peak) and fronto-parallel boxes (zero derivative -> "vertical
 plane" peak); the right image is the left one forward-warped by the rounded disparity, nearer
 surfaces winning, holes filled from the left neighbour.  Pure numpy, deterministic in (seed, frame).
+
+`scene` adds content that street scenes have and value noise does not (the nearest substitute for KITTI
+frames, which are not available offline):
+  "stripes"    a facade of exactly periodic vertical stripes, periods 8 / 16 / 24 px: repetitive texture, uniqueness rejections;
+  "saturated"  a saturated (255) and a black (0) patch in the left image: gray == 0 is the LR check's mask (oracle S8);
+  "pole"       a 1-px-wide and a 3-px-wide near pole in front of the ground plane: thin structures;
+  "wall"       a large textureless fronto-parallel wall.
 """
 import numpy as np
 
@@ -52,8 +59,29 @@ def _texture(w, h, salt, xoff):
     return np.clip(np.rint(img), 1, 255).astype(np.uint8)  # never 0: gray==0 is the reference's LR-check mask
 
 
-def ground_truth_disparity(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0):
+SCENES = ("road", "stripes", "saturated", "pole", "wall")
+
+
+def _scene_regions(w, h, scene, frame):
+    """(y0, y1, x0, x1) boxes of a scene's extra content; they move with the boxes of the road scene (2 px per frame)."""
+    s = 2 * frame
+    if scene == "stripes":
+        return [(int(0.30 * h), int(0.80 * h), max(0, int(0.08 * w) - s), max(0, int(0.46 * w) - s))]
+    if scene == "saturated":
+        return [(int(0.50 * h), int(0.70 * h), max(0, int(0.15 * w) - s), max(0, int(0.30 * w) - s)),
+                (int(0.62 * h), int(0.92 * h), max(0, int(0.55 * w) - s), max(0, int(0.75 * w) - s))]
+    if scene == "pole":
+        x1, x3 = max(0, int(0.37 * w) - s), max(0, int(0.61 * w) - s)
+        return [(int(0.25 * h), int(0.85 * h), x1, x1 + 1), (int(0.30 * h), int(0.90 * h), x3, x3 + 3)]
+    if scene == "wall":
+        return [(int(0.20 * h), int(0.75 * h), max(0, int(0.50 * w) - s), max(0, int(0.92 * w) - s))]
+    return []
+
+
+def ground_truth_disparity(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, scene="road"):
     """float disparity map of the LEFT view (pixels)."""
+    if scene not in SCENES:
+        raise ValueError(f"unknown scene {scene!r}: one of {SCENES}")
     dmax = min(min_disp + D - 2, 76)
     horizon = 0.45 * h
     y = np.arange(h, dtype=np.float64)[:, None]
@@ -70,12 +98,41 @@ def ground_truth_disparity(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0):
         x0, x1 = max(0, cx), min(w, cx + bw)
         if x1 > x0 and by1 > by0:
             d[by0:by1, x0:x1] = np.maximum(d[by0:by1, x0:x1], db)
+    if scene in ("stripes", "pole", "wall"):   # fronto-parallel surfaces standing on the ground: the ground's disparity at their foot
+        for y0, y1, x0, x1 in _scene_regions(w, h, scene, frame):
+            if x1 > x0:
+                d[y0:y1, x0:x1] = np.maximum(d[y0:y1, x0:x1], d[min(y1, h - 1), 0])
     return d
 
 
-def make_pair(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, channels=1):
+def _paint_scene(tex, scene, w, h, frame):
+    """The scene's extra content painted into the LEFT texture (the right image is warped from it afterwards)."""
+    regions = _scene_regions(w, h, scene, frame)
+    if scene == "stripes":
+        (y0, y1, x0, x1), = regions
+        third = max(1, (y1 - y0) // 3)
+        xs = np.arange(x0, x1) + 2 * frame   # stripes fixed to the facade, which moves with the scene
+        for k, period in enumerate((8, 16, 24)):
+            ya, yb = y0 + k * third, (y1 if k == 2 else y0 + (k + 1) * third)
+            # exactly periodic, no noise: the census of a stripe pixel repeats every `period` columns, so the matching cost has
+            # one minimum per period and only the aggregation's smoothness term (or nothing) picks among them
+            tex[ya:yb, x0:x1] = np.where((xs // (period // 2)) % 2 == 0, 70, 185).astype(np.uint8)[None, :]
+    elif scene == "saturated":
+        (ya, yb, xa, xb), (yc, yd, xc, xd) = regions
+        tex[ya:yb, xa:xb] = 255
+        tex[yc:yd, xc:xd] = 0      # gray == 0: the reference's LR-check mask (oracle S8)
+    elif scene == "pole":
+        for y0, y1, x0, x1 in regions:
+            tex[y0:y1, x0:x1] = 245
+    elif scene == "wall":
+        (y0, y1, x0, x1), = regions
+        tex[y0:y1, x0:x1] = 141
+    return tex
+
+
+def make_pair(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, channels=1, scene="road"):
     """-> (left, right, gt_disp): uint8 [h,w] (channels=1) or [h,w,3] BGR; gt float64 [h,w]."""
-    gt = ground_truth_disparity(w, h, D, min_disp, seed, frame)
+    gt = ground_truth_disparity(w, h, D, min_disp, seed, frame, scene)
     di = np.rint(gt).astype(np.int64)
     yy, xx = np.meshgrid(np.arange(h, dtype=np.int64), np.arange(w, dtype=np.int64), indexing="ij")
     xr = xx - di
@@ -90,7 +147,7 @@ def make_pair(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, channels=1):
     src = np.take_along_axis(np.where(hole, 0, src), idx, axis=1)
     lefts, rights = [], []
     for c in range(channels):
-        tex = _texture(w, h, seed + 1000003 * c, 2 * frame)
+        tex = _paint_scene(_texture(w, h, seed + 1000003 * c, 2 * frame), scene, w, h, frame)
         lefts.append(tex)
         rights.append(np.take_along_axis(tex, src, axis=1))
     if channels == 1:
@@ -98,9 +155,9 @@ def make_pair(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, channels=1):
     return np.stack(lefts, axis=-1), np.stack(rights, axis=-1), gt
 
 
-def make_batch(n, w, h, D, min_disp=4, seed=DEFAULT_SEED, channels=1, first_frame=0):
+def make_batch(n, w, h, D, min_disp=4, seed=DEFAULT_SEED, channels=1, first_frame=0, scene="road"):
     ls, rs = [], []
     for f in range(n):
-        l, r, _ = make_pair(w, h, D, min_disp, seed, first_frame + f, channels)
+        l, r, _ = make_pair(w, h, D, min_disp, seed, first_frame + f, channels, scene)
         ls.append(l); rs.append(r)
     return np.stack(ls), np.stack(rs)

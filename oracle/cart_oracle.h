@@ -5,7 +5,8 @@
  * and bench.py's cpu_baseline leg may include, link or call this library; the
  * product path (cart-slam_amd/) never routes through it.
  *
- * PARITY UNPINNED.  The reference (LorgeN/CART-SLAM) ships no tests, golden
+ * PARITY UNPINNED (tools/ref_pin/ is the kit that pins it on a machine with OpenCV-CUDA; tests/test_ref_pin.py
+ * consumes its outputs).  The reference (LorgeN/CART-SLAM) ships no tests, golden
  * vectors or fixtures for this path, cannot be built here (CUDA + OpenCV-CUDA
  * + Boost + log4cxx, none installed) and delegates the SGM core to the
  * un-vendored, un-pinned third-party module opencv_contrib `cudastereo`
@@ -54,8 +55,24 @@
  *                 integer disparity (not x16), never invalid.
  *  S7 median    3x3 on both maps as u16 (0xFFFF sorts highest); the one-pixel
  *                 image border passes through unfiltered.
+ *                 NOTE -- a build-owned choice [EXTERNAL-UNVERIFIED]: what the upstream median kernel leaves in the
+ *                 border row / column (pass-through, a replicated-border median, or untouched memory) cannot be
+ *                 checked here.  A replicated-border median changes 66-100 output pixels on the committed goldens and
+ *                 836-844 of 465 750 at 1242x375 (tests/spec_variants.py).  One place to change: the first `if` of
+ *                 cart_oracle_median3x3_u16 (and left_median_at / right_median_at in sgm_kernels.hip).
  *  S8 LR check  left pixel -> 0xFFFF if gray_left==0, or already 0xFFFF, or
  *                 k = x-(dL>>4) in [0,W) and |R(k)-(dL>>4)| > 1.
+ *                 NOTE -- probable point of departure [EXTERNAL-UNVERIFIED]: the check_consistency kernel of older libSGM
+ *                 releases, from which opencv_contrib's cudastereo was ported, tests
+ *                 `mask == 0 || d <= 0 || (k in range && |R(k) - d| > 1)` on the INTEGER disparity d = dL >> 4, which also
+ *                 invalidates every valid winner at disparity index 0; later libSGM releases test
+ *                 `org == INVALID_DISP` instead, which is the form above.  Which of the two cv::cuda::StereoSGM runs depends
+ *                 on the OpenCV version the reference was built with (un-versioned: CMakeLists.txt:19).  The `d <= 0` form
+ *                 would invalidate 558 / 789 / 1187 / 592 more pixels on the four committed goldens and 2225-2686 of
+ *                 465 750 on the 1242x375 scenes (tests/spec_variants.py).  One line to change in each place:
+ *                 cart_oracle_lr_check_range (`gray_left[i] == 0 || org == CART_ORACLE_WTA_INVALID` -> add
+ *                 `|| (org >> 4) == 0`) and post_kernel's `bool invalid =` line in sgm_kernels.hip.  tools/ref_pin produces the
+ *                 reference outputs that decide it; tests/test_ref_pin.py names this variant when they disagree.
  *  S9 range     0xFFFF -> (min_disp-1)*16, else += min_disp*16; stored s16.
  *  S10 post stages: Jacobi reads of the unmodified input, out-of-image samples
  *                 skipped by window means and making a difference INVALID.
