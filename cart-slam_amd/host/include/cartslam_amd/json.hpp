@@ -27,7 +27,11 @@ struct Value {
     }
     template <typename T> T get() const;
 };
-template <> inline int Value::get<int>() const { if (kind != Number) throw std::runtime_error("JSON value is not a number"); return (int)num; }
+template <> inline int Value::get<int>() const {
+    if (kind != Number) throw std::runtime_error("JSON value is not a number");
+    if (!(num >= -2147483648.0 && num <= 2147483647.0)) throw std::runtime_error("JSON number does not fit an int");   // also refuses NaN (the cast would be undefined)
+    return (int)num;
+}
 template <> inline double Value::get<double>() const { if (kind != Number) throw std::runtime_error("JSON value is not a number"); return num; }
 template <> inline bool Value::get<bool>() const { if (kind != Bool) throw std::runtime_error("JSON value is not a boolean"); return b; }
 template <> inline std::string Value::get<std::string>() const { if (kind != String) throw std::runtime_error("JSON value is not a string"); return str; }

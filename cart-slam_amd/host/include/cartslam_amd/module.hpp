@@ -35,6 +35,10 @@ class SystemModule {
     // for that frame is over -- after run() returned, threw, or was never started because a dependency failed.  Modules
     // that admit frames in id order (FrameOrder) use it to pass the turn of a frame that will never take it.
     virtual void frameFinished(uint32_t /*id*/) noexcept {}
+    // Extension as well: System::addModule tells the module the id of the first frame it will see (1 for a module list built
+    // before the first run; later for a module added to a running System), so that id-ordered modules do not wait for frames
+    // that ran before they existed.
+    virtual void attached(uint32_t /*firstFrameId*/) noexcept {}
 
     const std::vector<module_dependency_t> getRequiredData() const { return requiresData; }
     const std::vector<std::string> getProvidedData() const { return providesData; }

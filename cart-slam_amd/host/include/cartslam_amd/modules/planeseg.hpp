@@ -109,6 +109,7 @@ class SuperPixelDisparityPlaneSegmentationModule : public SyncWrapperSystemModul
                                                const unsigned int temporalSmoothingDistance = CARTSLAM_PLANE_TEMPORAL_DISTANCE_DEFAULT);
     system_data_t runInternal(System &system, SystemRunData &data) override;
     void frameFinished(uint32_t id) noexcept override { order.finish(id); }
+    void attached(uint32_t firstFrameId) noexcept override { order.startAt(firstFrameId); }
 
    private:
     void updatePlaneParameters(System &system, SystemRunData &data);  // sp_planeseg.cu:349-387

@@ -23,6 +23,7 @@ typedef uint16_t label_t;  // contourrelaxation/constants.hpp:35
 class FrameOrder {
    public:
     void finish(uint32_t id);   // idempotent: frame `id` has had (or will never take) its turn
+    void startAt(uint32_t id);  // the first frame that will ever arrive (default 1); frames below it are taken as over
     class Turn {
        public:
         Turn(FrameOrder &o, uint32_t id);
@@ -49,6 +50,7 @@ class SuperPixelModule : public SyncWrapperSystemModule {
     ~SuperPixelModule();
     system_data_t runInternal(System &system, SystemRunData &data) override;
     void frameFinished(uint32_t id) noexcept override { order.finish(id); }
+    void attached(uint32_t firstFrameId) noexcept override { order.startAt(firstFrameId); }
     unsigned int getBlockSize() const { return blockSize; }
 
    private:

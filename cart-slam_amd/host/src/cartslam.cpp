@@ -30,10 +30,11 @@ size_t WorkerPool::threadCount() {
 void WorkerPool::enqueue(std::function<void()> fn) {
     {
         std::lock_guard<std::mutex> lock(mutex);
-        queue.push_back(std::move(fn));
         // more queued tasks than idle workers to take them: one more thread (every queued task is guaranteed a worker
-        // without waiting for a running -- possibly blocked -- task to end)
-        if (queue.size() > idle) threads.emplace_back([this]() { work(); });
+        // without waiting for a running -- possibly blocked -- task to end).  The thread comes first: if it cannot be created
+        // (std::system_error under a pid limit) the caller gets the exception and nothing is left queued without a worker.
+        if (queue.size() + 1 > idle) threads.emplace_back([this]() { work(); });
+        queue.push_back(std::move(fn));
     }
     wake.notify_one();
 }
@@ -78,7 +79,11 @@ System::~System() {
     runCondition.wait(lock, [this] { return activeRuns == 0; });
 }
 
-void System::addModule(std::shared_ptr<SystemModule> module) { modules.push_back(module); }
+void System::addModule(std::shared_ptr<SystemModule> module) {
+    std::unique_lock<std::mutex> lock(runMutex);
+    module->attached(runId + 1);   // a module added to a running System starts with the next frame, not with frame 1
+    modules.push_back(module);
+}
 
 std::shared_ptr<SystemRunData> System::getRunById(const uint32_t id) {
     std::unique_lock<std::mutex> lock(runMutex);
@@ -119,15 +124,33 @@ std::future<void> System::run() {
         while (runs.size() > runRetention && runs.front()->id + maxBackOffset < oldestActive) runs.erase(runs.begin());
         ++activeRuns;
     }
-    auto mods = modules;
+    std::vector<std::shared_ptr<SystemModule>> mods;
+    {
+        std::unique_lock<std::mutex> lock(runMutex);
+        mods = modules;
+    }
+    // the frame could not be handed to the pool (thread creation failed): take it back, and tell every module that this id
+    // will never come, so that id-ordered modules do not wait for it
+    auto abandon = [this, run, &mods]() {
+        for (const auto &m : mods) m->frameFinished(run->id);
+        {
+            std::unique_lock<std::mutex> lock(runMutex);
+            --activeRuns;
+            activeIds.erase(run->id);
+        }
+        runCondition.notify_all();
+    };
+    try {
     return threadPool.post([this, run, mods]() {
         auto frameTiming = timing::initTiming("Frame", run->id);  // cartslam.cpp:245-251
         timing::startTiming(frameTiming);
         std::exception_ptr first;
         std::vector<std::future<void>> done;
-        for (const auto &m : mods) {
+        for (size_t mi = 0; mi < mods.size(); ++mi) {
+            const auto &m = mods[mi];
             // every module gets its own waiter: dependencies first (cartslam.cpp:96-167), then the module, then the
             // returned (key, ptr) pairs go onto the frame's blackboard (cartslam.cpp:279-301)
+            try {
             done.push_back(threadPool.post([this, run, m]() {
                 auto moduleTiming = timing::initTiming(m->name, run->id);  // cartslam.cpp:259-262: init before the dependency wait
                 struct Finished {   // the module hears about the end of this frame on every way out, exceptions included
@@ -147,6 +170,11 @@ std::future<void> System::run() {
                 for (const auto &kv : out) run->insertData(kv);
                 timing::endTiming(moduleTiming);  // :290
             }));
+            } catch (...) {   // this waiter and the ones after it never start: their modules hear that the frame is over
+                if (!first) first = std::current_exception();
+                for (size_t k = mi; k < mods.size(); ++k) mods[k]->frameFinished(run->id);
+                break;
+            }
         }
         for (auto &f : done) {
             try { f.get(); } catch (...) { if (!first) first = std::current_exception(); }
@@ -160,5 +188,9 @@ std::future<void> System::run() {
         runCondition.notify_all();
         if (first) std::rethrow_exception(first);
     });
+    } catch (...) {
+        abandon();
+        throw;
+    }
 }
 }  // namespace cart

@@ -7,6 +7,13 @@ namespace {
 struct Parser {
     const std::string &s;
     size_t i = 0;
+    int depth = 0;   // open arrays / objects: bounded, so that a hostile file cannot overflow the stack (found by fuzz_readers under ASan)
+    static constexpr int kMaxDepth = 64;
+    struct Nest {
+        Parser &p;
+        explicit Nest(Parser &p) : p(p) { if (++p.depth > kMaxDepth) p.err("nesting deeper than 64 levels"); }
+        ~Nest() { --p.depth; }
+    };
     explicit Parser(const std::string &s) : s(s) {}
     [[noreturn]] void err(const std::string &m) { throw std::runtime_error("JSON parse error at offset " + std::to_string(i) + ": " + m); }
     void ws() { while (i < s.size() && std::isspace((unsigned char)s[i])) ++i; }
@@ -16,6 +23,7 @@ struct Parser {
         const char c = s[i];
         Value v;
         if (c == '{') {
+            Nest nest(*this);
             v.kind = Value::Object; ++i; ws();
             if (i < s.size() && s[i] == '}') { ++i; return v; }
             for (;;) {
@@ -33,6 +41,7 @@ struct Parser {
             }
         }
         if (c == '[') {
+            Nest nest(*this);
             v.kind = Value::Array; ++i; ws();
             if (i < s.size() && s[i] == ']') { ++i; return v; }
             for (;;) {

@@ -396,6 +396,16 @@ FrameOrder::Turn::Turn(FrameOrder &o, uint32_t id) : order(o), id(id) {
 }
 FrameOrder::Turn::~Turn() { order.finish(id); }
 
+void FrameOrder::startAt(uint32_t id) {
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        if (id <= next) return;
+        next = id;
+        while (!finishedAhead.empty() && *finishedAhead.begin() <= next) { if (*finishedAhead.begin() == next) ++next; finishedAhead.erase(finishedAhead.begin()); }
+    }
+    cv.notify_all();
+}
+
 void FrameOrder::finish(uint32_t id) {
     {
         std::lock_guard<std::mutex> lock(mutex);

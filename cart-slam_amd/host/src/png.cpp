@@ -41,6 +41,7 @@ bool readPng(const std::string &path, HostImage &out) {
         pos += 12 + len;
     }
     int sch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+    if (w > 16384 || h > 16384) throw std::runtime_error("PNG larger than 16384 x 16384 (the engine's limit): " + path);   // before any allocation sized by the header
     if (w <= 0 || h <= 0 || depth != 8 || sch == 0 || interlace != 0) throw std::runtime_error("unsupported PNG (need 8-bit, non-interlaced, gray/RGB[A]): " + path);
     const size_t stride = (size_t)w * sch;
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);

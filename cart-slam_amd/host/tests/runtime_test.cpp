@@ -74,6 +74,22 @@ class ModuleC : public SyncWrapperSystemModule {
     }
     std::atomic<int> calls{0};
 };
+// takes its frames in id order (like the superpixel and plane modules); records the order
+class ModuleOrdered : public SyncWrapperSystemModule {
+   public:
+    ModuleOrdered() : SyncWrapperSystemModule("Ordered") { providesData.push_back("o"); }
+    system_data_t runInternal(System &, SystemRunData &data) override {
+        FrameOrder::Turn turn(order, data.id);
+        std::lock_guard<std::mutex> lock(m);
+        seen.push_back(data.id);
+        return MODULE_RETURN_SHARED("o", long, (long)data.id);
+    }
+    void frameFinished(uint32_t id) noexcept override { order.finish(id); }
+    void attached(uint32_t first) noexcept override { order.startAt(first); }
+    FrameOrder order;
+    std::mutex m;
+    std::vector<uint32_t> seen;
+};
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -184,6 +200,30 @@ int main(int argc, char **argv) {
         bool ascending = true;
         for (size_t i = 1; i < sequence.size(); ++i) ascending &= sequence[i] > sequence[i - 1];
         CHECK(ascending);
+    }
+    // 1d. an id-ordered module added to a System that has ALREADY run frames: it starts with the next frame instead of waiting
+    //     for frames 1..20, which it will never be given (a hang here is the failure)
+    {
+        auto src = std::make_shared<CountingSource>(60);
+        auto sys = std::make_shared<System>(src, CARTSLAM_RUN_RETENTION, 12);
+        sys->addModule<ModuleA>();
+        std::deque<std::future<void>> fs;
+        for (int i = 0; i < 20; ++i) fs.push_back(sys->run());
+        for (auto &f : fs) f.get();
+        fs.clear();
+        sys->addModule<ModuleOrdered>();
+        while (!src->isFinished()) fs.push_back(sys->run());
+        bool hung = false;
+        for (auto &f : fs)
+            if (f.wait_for(std::chrono::seconds(30)) != std::future_status::ready) { hung = true; break; } else f.get();
+        CHECK(!hung);
+        auto ordered = sys->getModule<ModuleOrdered>();
+        std::lock_guard<std::mutex> lock(ordered->m);
+        CHECK(ordered->seen.size() == 40 && ordered->seen.front() == 21 && ordered->seen.back() == 60);
+        bool ascending = true;
+        for (size_t i = 1; i < ordered->seen.size(); ++i) ascending &= ordered->seen[i] == ordered->seen[i - 1] + 1;
+        CHECK(ascending);
+        if (hung) { std::printf("FAILED: frames behind a late id-ordered module never finished\n"); return 1; }
     }
     // 2. the System: consumers listed before their providers, 12 frames in flight, retention 32
     const int frames = 400;

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "_build", "libcart_oracle.so")
+LIB = os.environ.get("CART_ORACLE_LIB") or os.path.join(ORACLE_DIR, "_build", "libcart_oracle.so")   # override: sanitizer builds (make -C oracle sanitize)
 
 
 class SgmParams(C.Structure):
@@ -30,6 +30,8 @@ _lib = None
 
 
 def build():
+    if os.environ.get("CART_ORACLE_LIB"):
+        return
     src_time = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("cart_oracle.c", "cart_oracle_sp.c", "cart_oracle.h"))
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < src_time:
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
