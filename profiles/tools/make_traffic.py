@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Adds the HBM traffic of one configuration's aggregate / WTA launches to profiles/traffic.json.
-usage: make_traffic.py <pmc_summary.txt> <W> <H> <D> <P> <frames per launch> <plan>
+usage: make_traffic.py <pmc_summary.txt> <W> <H> <D> <P> <frames per launch> <plan> [round]
 Input = profiles/pmc_summary.py output holding FETCH_SIZE and WRITE_SIZE means (KB per dispatch, separate --pmc passes).
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE counts 128-byte requests at 64 bytes -> doubled;
 WRITE_SIZE is exact for 16-byte-per-lane streaming stores."""
@@ -10,6 +10,7 @@ import re
 import sys
 
 summary, w, h, D, P, fpl, plan = sys.argv[1], *(int(v) for v in sys.argv[2:7]), sys.argv[7]
+rnd = int(sys.argv[8]) if len(sys.argv) > 8 else 3
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.path.join(root, "profiles", "traffic.json")
 tj = json.load(open(path)) if os.path.exists(path) else {}
@@ -34,6 +35,6 @@ for k, v in vals.items():
         continue
     tj[f"{name}_{w}x{h}_D{D}_P{P}_B{fpl}{suffix}"] = {
         "kernel": k.replace("void cart_amd::", ""), "fetch_size_kb_raw": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
-        "hbm_bytes_per_launch": int(round(v["WRITE_SIZE"] * 1024 + 2 * v["FETCH_SIZE"] * 1024)), "alg_bytes_per_launch": alg, "round": 2}
+        "hbm_bytes_per_launch": int(round(v["WRITE_SIZE"] * 1024 + 2 * v["FETCH_SIZE"] * 1024)), "alg_bytes_per_launch": alg, "round": rnd}
 json.dump(tj, open(path, "w"), indent=1)
 print("updated", path, [k for k in tj if k != "_note"])
