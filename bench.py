@@ -279,6 +279,8 @@ def run(args, world, rank, dev_index):
     elapsed = sorted(blocks)[len(blocks) // 2]
     stages, ncalls = eng.collect_timing()
     eng.set_timing(False)
+    if plan["plan"] == "pairs" and eng.device_status() != 0:   # the experimental plan's bounded hand-over poll gave up: outputs invalid
+        sys.exit(f"bench.py: rank {rank}: a pair sweep timed out waiting for its neighbour block (cart_engine_device_status != 0)")
     # what the LAST timed step produced for the first and the last frame of this rank's batch (checked against the oracle
     # below, outside every timed region)
     check_frames = sorted({0, B - 1})

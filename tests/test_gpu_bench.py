@@ -1,0 +1,61 @@
+"""bench.py as the driver runs it (GPU): one JSON line on stdout and nothing else, the contract's keys, the self-check of the
+timed output, and the multi-rank form -- `python -m torch.distributed.run ... bench.py --gpus 2` -- rehearsed with two gloo
+ranks sharing the one GPU a lease has (RCCL refuses two ranks on one device; the rank logic, the barriers, the max over ranks,
+the histogram exchange and the sequence leg are the same code)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "3", "--warmup", "1", "--repeats", "3", "--batch", "4", "--width", "320", "--height", "96", "--disparities", "64", "--no-pcie"]
+
+
+def one_json_line(stdout):
+    lines = [l for l in stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}:\n" + "\n".join(l[:200] for l in lines[:8])
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_is_verified_and_complete():
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    d = one_json_line(pr.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "spread", "repeats", "prewarm_steps", "verified"):
+        assert k in d, k
+    assert d["verified"] is True and d["verification"]["mismatches"] == []
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["repeats"] == 3 and d["value"] > 0
+    assert d["spread"]["min"] <= d["value"] <= d["spread"]["max"]
+    assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # value = pairs of the median block / its time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["frac_of_copy_ceiling"] is None or r["frac_of_copy_ceiling"] <= 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["config"]["distinct_frames_per_batch"] == 4
+
+
+def test_two_ranks_through_the_drivers_launch_form():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allow-shared-gpu", "--sequence", "--no-cpu-baseline"] + SMALL
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    d = one_json_line(pr.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_pairs_per_step"] == 8 and d["config"]["world_size"] == 2
+    assert d["scaling"] == "weak" and d["verified"] is None and "cpu_baseline" not in d
+    assert d["sequence_mode"]["frames"] == 8 and d["sequence_mode"]["pairs_per_s"] > 0
+
+
+def test_self_launch_refuses_more_gpus_than_the_box_has():
+    import torch
+    n = torch.cuda.device_count() + 1
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + SMALL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert pr.returncode == 2 and b"GPUs" in pr.stderr and pr.stdout.strip() == b""
