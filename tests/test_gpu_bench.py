@@ -54,6 +54,18 @@ def test_two_ranks_through_the_drivers_launch_form():
     assert d["sequence_mode"]["frames"] == 8 and d["sequence_mode"]["pairs_per_s"] > 0
 
 
+def test_self_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without RANK in the environment: bench.py starts the two ranks itself (launch_ranks) and relays
+    rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allow-shared-gpu", "--no-cpu-baseline"] + SMALL,
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    d = one_json_line(pr.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+
+
 def test_self_launch_refuses_more_gpus_than_the_box_has():
     import torch
     n = torch.cuda.device_count() + 1
