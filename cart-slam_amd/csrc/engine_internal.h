@@ -76,6 +76,7 @@ void launch_census(const ImageBatch &left, const ImageBatch &right, int channels
                    uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l, uint32_t *cen_r, uint32_t *right_pk,
                    const Geometry &g, hipStream_t s);
 int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is owned by D/16 lanes)
+int agg_residency_cap(int ndirs, int D, int n_frames);  // 4-wave aggregation workgroups allowed per CU at a time, 0 = uncapped (measured table at its definition)
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
                 int n_frames, hipStream_t s);

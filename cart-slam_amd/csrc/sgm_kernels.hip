@@ -696,27 +696,34 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
 
 int agg_lines_per_block(int D) { return 64 * kAggWaves / (D / 16); }
 
+// 4-wave workgroups of the aggregation launch allowed per CU at a time (0 = no cap: 7 fit).  One row per measured case
+// (ms per launch, residency 7 / 5 / 4 / 3 / 2; round 2, one box per row -- DESIGN.md 4.1):
+//   ndirs <= 4 (half the work is W-step horizontal scans)
+//     D = 64   0.52-0.63 / 0.52-0.57 / - / 0.49-0.51 / 0.52; with the second stream on: 2 per CU 1.04-1.10 ms per step, 3 per CU 1.13-1.18  -> 2
+//     D = 128  1.00-1.07 / - / 0.86 / 0.82 / -; with the second stream: 3 per CU 1.68-1.75, 2 per CU 1.72-1.77                                  -> 3
+//     D = 256  1.215 / - / 1.19 / - / 1.23 (3 directions + fused sweep)                                                                          -> 4
+//   ndirs 7-8
+//     D = 256  3.51 / - / 3.29 / - / 3.56 (1080p, 4 frames)                                                                                      -> 4
+//     D <= 128, fewer than 16 frames (the frame loop's coalesced groups): 4.73-4.88 k pairs/s against 4.54-4.61 k                              -> 4
+//     D <= 128, 16 frames (the headline): 1.574 / 1.547 / 1.540 / 1.60 / 1.69 alone, but beside the second stream's plane kernels the cap
+//       costs 1 % (1.61-1.68 against 1.59-1.63)                                                                                                  -> none
+int agg_residency_cap(int ndirs, int D, int n_frames) {
+    if (ndirs <= 4) return D <= 64 ? 2 : D <= 128 ? 3 : 4;
+    return (D >= 256 || n_frames < 16) ? 4 : 0;
+}
+
 void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     AggArgs a = a_in;
     a.n_frames = n_frames;
     dim3 grid(a.blocks_per_frame * n_frames), block(64 * kAggWaves);
-    // A cap on the workgroups resident per CU, enforced with unused dynamic LDS: the others are dispatched as slots free
-    // up.  With everything resident at once (7 waves per SIMD fit) the CUs that hold the W-step horizontal scans end up
-    // with as many of the short vertical / diagonal scans as the others and finish last; with 3-4 workgroups per CU the
-    // dispatcher hands the short scans to whichever CU is free, the long scans keep most of their SIMD, and the census
-    // planes the directions re-read stay in L2.  Aggregate launch in ms, 7 resident / 5 / 4 / 3 / 2 (r02_agg_residency*.sh):
-    //   D=128 P=8          1.574 / 1.547 / 1.540 / 1.60 / 1.69      D=256 P=4 (3 directions) 1.215 / - / 1.19 / - / 1.23
-    //   1080p D=256 P=8    3.51  /  -    / 3.29  /  -   / 3.56      D=64 P=4   0.52-0.63 / 0.52-0.57 / - / 0.49-0.51 / 0.52
-    //   D=128 P=4          1.00-1.07 / - / 0.86 / 0.82 / -
-    // -> 4 per CU, 3 (D=128) or 2 (D=64) for launches of at most four directions (their horizontal scans are half the work).  The
-    // exception is the 7-8 direction launch at D <= 128: beside the plane stages of the previous batch on the second stream
-    // (the bench's default) the cap costs a 16-frame launch 1 % (1.61-1.68 against 1.59-1.63 ms), so that one keeps
-    // everything resident; the frame loop's launches of ~6 frames gain 5 % from it (4.73-4.88 against 4.54-4.61 k pairs/s).
+    // A cap on the workgroups resident per CU (agg_residency_cap above), enforced with unused dynamic LDS: the others are
+    // dispatched as slots free up.  With everything resident at once (7 waves per SIMD fit) the CUs that hold the W-step
+    // horizontal scans end up with as many of the short vertical / diagonal scans as the others and finish last; with 2-4
+    // workgroups per CU the dispatcher hands the short scans to whichever CU is free, the long scans keep most of their SIMD,
+    // and the census planes the directions re-read stay in L2.  Smaller workgroups are slower (two waves or one: the headline's
+    // launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64.
     constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
-    // With the second stream on (the default) D=64 P=4 is faster still with two per CU: 1.04-1.10 against 1.13-1.18 ms per
-    // step (r02_agg_residency6.sh; D=128 P=4: 1.72-1.77 with two, 1.68-1.75 with three).  Smaller workgroups are slower (two
-    // waves or one: the headline's launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64 (r02_agg_waves.sh).
-    const int resident = (a.ndirs <= 4 ? (a.g.D <= 64 ? 2 : a.g.D <= 128 ? 3 : 4) : (a.g.D >= 256 || n_frames < 16 ? 4 : 0)) * 4 / kAggWaves;   // counted in 4-wave workgroups
+    const int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
     const int lpp = a.g.D / 16;
     const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
     // (never more than 64 KB per workgroup in all, the limit that needs no opt-in: two of those per CU are still two)
