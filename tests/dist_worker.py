@@ -67,9 +67,10 @@ def main():
         else:
             assert got["disparity"] is None and got["planes"] is None
         next_id += n_seq
-        # pipelined sequence mode: three sequences submitted back to back (the middle one one frame longer: the first rank
-        # then holds one frame more), results asked for afterwards
-        lengths = [n_seq, n_seq + 1, n_seq]
+        # pipelined sequence mode: four sequences submitted back to back (one a frame longer: the first rank then holds one
+        # frame more; one of a single frame: the second rank then has nothing to compute and only joins the exchange),
+        # results asked for afterwards
+        lengths = [n_seq, n_seq + 1, 1, n_seq]
         handles = []
         for n in lengths:
             sl = sr = None

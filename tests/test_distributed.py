@@ -207,7 +207,7 @@ def _pipeliner_worker(rank, world, port, lengths, q):
             for i, n in enumerate(lengths):
                 l, r = seqs[i]
                 who = (torch.arange(n) % world)[:, None, None]
-                want_d = l.to(torch.int16) * 2 - r.to(torch.int16) + 100 * (i + 1)
+                want_d = l.to(torch.int16) * 2 - r.to(torch.int16) + 100 * (i + 1)   # every rank has made i + 1 calls, with or without frames
                 want_p = ((l.to(torch.int32) + r.to(torch.int32) + who) % 3).to(torch.uint8)
                 for mode in got:
                     ok &= torch.equal(got[mode][i]["disparity"], want_d) and torch.equal(got[mode][i]["planes"], want_p)
@@ -218,12 +218,14 @@ def _pipeliner_worker(rank, world, port, lengths, q):
         dist.destroy_process_group()
 
 
-def test_pipelined_sequences_equal_one_at_a_time_world_2():
-    """SequencePipeliner over gloo, two ranks: four back-to-back sequences (even, odd, shorter than the world, even) give the
-    same gathered outputs whether each is waited for before the next is submitted or all are submitted first -- the order in
-    which scatter(i+1) and gather(i) are posted is the same on both ranks, so no collective can pair with the wrong one."""
-    results, _ = _spawn(_pipeliner_worker, 2, ((8, 7, 1, 6),))
-    assert sorted(r for r, _ in results) == [0, 1] and all(ok for _, ok in results)
+@pytest.mark.parametrize("world,lengths", [(2, (8, 7, 1, 6)), (4, (13, 3, 16, 5))])
+def test_pipelined_sequences_equal_one_at_a_time(world, lengths):
+    """SequencePipeliner over gloo, two and four ranks: four back-to-back sequences (lengths that divide, that leave a
+    remainder, and that are shorter than the world, so that some ranks hold no frame at all) give the same gathered outputs
+    whether each is waited for before the next is submitted or all are submitted first -- the order in which scatter(i+1) and
+    gather(i) are posted is the same on every rank, so no collective can pair with the wrong one."""
+    results, _ = _spawn(_pipeliner_worker, world, (lengths,))
+    assert sorted(r for r, _ in results) == list(range(world)) and all(ok for _, ok in results)
 
 
 def _dead_peer_worker(rank, world, port, q):

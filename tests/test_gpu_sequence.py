@@ -89,8 +89,8 @@ def _free_port():
 
 @pytest.mark.parametrize("device_schedule", [1, 0])
 def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
-    """tests/dist_worker.py x 2 (gloo, one GPU) vs one process: every frame of every step, of the sequence call and of three
-    pipelined sequences (one of uneven length: rank 0 holds one frame more)."""
+    """tests/dist_worker.py x 2 (gloo, one GPU) vs one process: every frame of every step, of the sequence call and of four
+    pipelined sequences (one of uneven length: rank 0 holds one frame more; one of a single frame: rank 1 holds none)."""
     import torch
     from cartslam import Engine
     from cartslam.pipeline import StereoPipeline
@@ -112,7 +112,7 @@ def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
     pipe = StereoPipeline(eng, provider="histogram_peak", update_interval=ui, reset_interval=ri, with_ccl=True, device_schedule=bool(device_schedule))
     n_step = n_local * world
     # the batch boundaries of the ranks' run: `steps` batches, the sequence call, then the three pipelined sequences
-    sizes = [n_step] * (steps + 1) + [n_step, n_step + 1, n_step]
+    sizes = [n_step] * (steps + 1) + [n_step, n_step + 1, 1, n_step]
     total = sum(sizes)
     seen, first = 0, 1
     for s, size in enumerate(sizes):
