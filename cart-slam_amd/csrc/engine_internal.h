@@ -44,6 +44,7 @@ struct AggArgs {
     int ndirs;
     int blocks_per_frame;
     int n_frames;        // filled by launch_aggregate
+    int xcd_frames;      // filled by launch_aggregate: decode the grid per XCD (frames x, x + 8, ... on XCD x)
     DirDesc dirs[kMaxPaths];
 };
 

@@ -462,6 +462,9 @@ template <int LPP> constexpr int v_depth() { return LPP == 4 ? CART_VDEPTH4 : LP
 #ifndef CART_AGG_WAVES
 #define CART_AGG_WAVES 4
 #endif
+#ifndef CART_XCD_REMAP
+#define CART_XCD_REMAP 1   // 0: experiment builds only (A/B of the XCD-aware grid decode)
+#endif
 constexpr int kAggWaves = CART_AGG_WAVES;   // waves per workgroup: nothing in the kernel is shared between waves
 template <int LPP>
 __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
@@ -475,13 +478,19 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
 #endif
     // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
     // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
+    // XCD placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its
+    // own, and every direction re-reads its frame's census planes (4.2 MB per frame).  With n_frames a multiple of 8 the
+    // grid is decoded per XCD (xcd_placement() below): XCD x works on frames x, x + 8, ... in the same direction-major order,
+    // so that a frame's planes are fetched into ONE L2 instead of all eight.
+    int bid = (int)blockIdx.x, nfr = a.n_frames, frame0 = 0, fstep = 1;
+    if (a.xcd_frames) { frame0 = bid & 7; bid >>= 3; nfr = a.n_frames >> 3; fstep = 8; }
     int di = 0;
     for (int i = 1; i < a.ndirs; ++i)
-        if ((int)blockIdx.x >= a.dirs[i].blk0 * a.n_frames) di = i;
+        if (bid >= a.dirs[i].blk0 * nfr) di = i;
     const int nblk = (a.dirs[di].nlines + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK;
-    const int rb = blockIdx.x - a.dirs[di].blk0 * a.n_frames;
-    const int frame = rb / nblk;
-    const int b = rb - frame * nblk + a.dirs[di].blk0;
+    const int rb = bid - a.dirs[di].blk0 * nfr;
+    const int frame = frame0 + fstep * (rb / nblk);
+    const int b = rb - (rb / nblk) * nblk + a.dirs[di].blk0;
     const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
     const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP;  // lane inside the pixel's lane group, pixel group inside the wave
@@ -696,6 +705,14 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
 
 int agg_lines_per_block(int D) { return 64 * kAggWaves / (D / 16); }
 
+// XCD-aware grid decode of the aggregation launch and the fused sweep: on when the launch's frames divide over the 8 XCDs and
+// one frame's two census planes are of the order of an XCD's 4 MB L2.  Measured A/B on one box (profiles/r03_xcd.txt):
+// 1242x375 D=128 P=8 aggregate 1.607-1.613 vs 1.619-1.631 ms (+0.7 % pairs/s), D=256 P=4 aggregate 1.21-1.23 vs 1.25-1.26,
+// D=64 P=4 level; at 1920x1080 (17 MB of census per frame) it costs the aggregate 7 % (7.83 vs 7.32 ms per 8 frames): off there.
+bool xcd_placement(const Geometry &g, int n_frames) {
+    return CART_XCD_REMAP && n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);
+}
+
 // 4-wave workgroups of the aggregation launch allowed per CU at a time (0 = no cap: 7 fit).  One row per measured case
 // (ms per launch, residency 7 / 5 / 4 / 3 / 2; round 2, one box per row -- DESIGN.md 4.1):
 //   ndirs <= 4 (half the work is W-step horizontal scans)
@@ -715,6 +732,7 @@ int agg_residency_cap(int ndirs, int D, int n_frames) {
 void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     AggArgs a = a_in;
     a.n_frames = n_frames;
+    a.xcd_frames = xcd_placement(a.g, n_frames) ? 1 : 0;
     dim3 grid(a.blocks_per_frame * n_frames), block(64 * kAggWaves);
     // A cap on the workgroups resident per CU (agg_residency_cap above), enforced with unused dynamic LDS: the others are
     // dispatched as slots free up.  With everything resident at once (7 waves per SIMD fit) the CUs that hold the W-step
@@ -1312,6 +1330,7 @@ struct FusedArgs {
     uint32_t *partial;   // [frame][block][sweep step][rv_row_slots] u16 right-view minima of every block (rv_key16; last slot of a row: unused sink)
     Geometry g;
     float uniq;
+    int xcd_frames;      // xcd_placement(): blocks are decoded per XCD
 };
 constexpr int kUpPath = 1;   // slab index of the direction computed here and never stored (oracle order: down, up, ...)
 
@@ -1343,7 +1362,11 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     __shared__ uint16_t s_thr[NTHR];             // uniqueness threshold by best cost
     const Geometry &g = a.g;
     const int nblk = (g.w + COLS - 1) / COLS;
-    const int frame = blockIdx.x / nblk, blk = blockIdx.x - frame * nblk, x0 = blk * COLS;
+    // same XCD placement as aggregate_kernel (frames x, x + 8, ... on XCD x): the sweep re-reads the census planes the
+    // aggregation launch has just pulled into that XCD's L2
+    int bid = (int)blockIdx.x, frame0 = 0, fstep = 1;
+    if (a.xcd_frames) { frame0 = bid & 7; bid >>= 3; fstep = 8; }
+    const int frame = frame0 + fstep * (bid / nblk), blk = bid - (bid / nblk) * nblk, x0 = blk * COLS;
     const int hpad = (g.h + RB - 1) / RB * RB + RB;   // rows of one block in the partial buffer (see flush)
     const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP, d0 = gl * 16;
@@ -1625,7 +1648,7 @@ size_t wta_fused_partial_elems(const Geometry &g) {
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s) {
-    FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq};
+    FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq, xcd_placement(g, n_frames) ? 1 : 0};
     const int wpb = fused_waves_for(g), cols = wpb * (64 / (g.D / 16));
     const int nblk = (g.w + cols - 1) / cols;
     dim3 grid(nblk * n_frames), block(64 * wpb);
