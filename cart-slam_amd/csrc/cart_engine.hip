@@ -57,6 +57,7 @@ struct cart_engine {
     cart_engine_params params;
     Geometry g;
     float uniq;
+    uint16_t *uniq_thr = nullptr;   // device: integer uniqueness threshold of every best cost 0..2047 for this engine's ratio (WTA kernels)
     // workspaces, each [max_inflight][...]
     uint8_t *gray_l = nullptr, *gray_r = nullptr;
     uint32_t *cen_l = nullptr, *cen_r = nullptr;      // point `cen_slack` elements into their allocations
@@ -322,6 +323,10 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
             cart_engine_destroy(e);
             return fail("hipEventCreate failed");
         }
+    // the WTA kernels' uniqueness test as a table: uniq_threshold() evaluated once per cost by the device function itself
+    if (dev_alloc(&e->uniq_thr, 2048)) { cart_engine_destroy(e); return -1; }
+    launch_uniq_table(e->uniq, e->uniq_thr, nullptr);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { cart_engine_destroy(e); return fail("building the uniqueness table failed"); }
     build_agg_args(e, e->agg, 0xffu);
     build_agg_args(e, e->agg_fused, 0xffu & ~(1u << 3));  // launch-order slot 3 = {0,-1} = "up" (slab kFusedUpPath)
     build_agg_args(e, e->agg_pairs, 0x63u);               // launch-order slots 0, 1 (right, left), 5 (down-left), 6 (up-left)
@@ -343,7 +348,7 @@ void cart_engine_destroy(cart_engine *e) {
     (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
     void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
-                    e->pair_xch, e->pair_ticket, e->dev_status};
+                    e->pair_xch, e->pair_ticket, e->dev_status, e->uniq_thr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots) {
@@ -569,9 +574,9 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
         STAGE("wta");
-        if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq, n, st);
-        else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq, n, st);
-        else launch_wta(slabs, wl, rpk, g, e->uniq, n, st);
+        if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq_thr, n, st);
+        else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, st);
+        else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, st);
         STAGE("post");
         if (!smooth) {
             launch_post(wl, rpk, gl, o, g, n, st);

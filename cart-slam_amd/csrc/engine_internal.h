@@ -79,14 +79,15 @@ void launch_census(const ImageBatch &left, const ImageBatch &right, int channels
 int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is owned by D/16 lanes)
 int agg_residency_cap(int ndirs, int D, int n_frames);  // 4-wave aggregation workgroups allowed per CU at a time, 0 = uncapped (measured table at its definition)
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
-void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
+// thr = device table of the integer uniqueness threshold for every best cost 0..2047 (launch_uniq_table, built once per engine)
+void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s);
 // plan PAIRS (sgm_kernels.hip): one sweep per vertical direction carries that direction and the diagonal leaning the same way
 size_t pair_xch_elems(const Geometry &g);   // 8-byte words of the per-frame hand-over buffer
 void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
                        const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s);
 void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
-                      const Geometry &g, float uniq, int n_frames, hipStream_t s);
+                      const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
 // The sweep addresses its slab stores as "wave-uniform base + 32-bit lane offset"; lanes of columns >= w are sent to the
 // same cell of the sink slab, (sink - out) <= 4 slabs further on.  That offset plus one image row of columns has to fit 32
 // bits (w*h*D < ~2^30: e.g. 2048x2048 at D=256 and 4096x2160 at D=128 do not); plan_for() gives such engines FUSED_UP.
@@ -95,7 +96,7 @@ inline bool pairs_offsets_fit(const Geometry &g) { return 4 * (unsigned long lon
 constexpr int kFusedUpPath = 1;
 size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
-                      uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s);
+                      uint32_t *partial, const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
 void launch_uniq_table(float u, uint16_t *out_dev, hipStream_t s);   // test access to the integer uniqueness threshold
 void uniq_table_host(float u, uint16_t *out);
 void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames, hipStream_t s);

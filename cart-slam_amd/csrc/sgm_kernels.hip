@@ -1098,7 +1098,7 @@ struct WtaArgs {
     uint16_t *wta_l;
     uint32_t *right_pk;
     Geometry g;
-    float uniq;
+    const uint16_t *thr;             // integer uniqueness threshold by best cost, 2048 entries (uniq_threshold of every cost, built at engine create)
     int nslabs;
     int slab_idx[kMaxPaths];
 };
@@ -1115,7 +1115,6 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     uint16_t *wta_l = a.wta_l;
     uint32_t *right_pk = a.right_pk;
     const Geometry &g = a.g;
-    const float uniq = a.uniq;
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
     const int grp = threadIdx.x / LPP, gl = threadIdx.x % LPP, d0 = gl * 16;
     // Right view: every lane min-reduces its 16 (S << 16 | d) keys into the tile's array indexed by p = x - d (ds_min_u32),
@@ -1131,7 +1130,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         __syncthreads();
     }
 
-    uint32_t pk_res[NPASS], tot_res[NPASS];
+    uint32_t pk_res[NPASS], tot_res[NPASS], thr_res[NPASS];
     constexpr bool PREFETCH = NPASS >= 4;
     v4u pf[PREFETCH ? 2 : 1][PREFETCH ? kMaxPaths : 1];
     auto issue_pass = [&](int pass, v4u (&dst)[PREFETCH ? kMaxPaths : 1]) {
@@ -1215,13 +1214,17 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
         uint32_t pk = ((m >> 4) << 16) | (uint32_t)(d0 + (int)(m & 15u));
         pk = group_allmin<LPP>(pk);
-        const uint32_t T = uniq_threshold(pk >> 16, uniq);
+        // = uniq_threshold(best cost): one load from the engine's 4 KB table (L1-resident) instead of the float search -- a
+        // division and five multiply-compares, ~45 VALU instructions per lane and pass, twice (here and where the pixel's
+        // first lane decides), about a quarter of this kernel's instructions; at D = 64 the kernel is as much VALU- as HBM-bound
+        const uint32_t T = a.thr[pk >> 16];
         const uint32_t tt = T * 0x10001u;
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
         tot_res[pass] = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         pk_res[pass] = pk;
+        thr_res[pass] = T;
     }
     __syncthreads();
 
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
             const int xl = pass * PPP + grp, x = x0 + xl;
             if (x >= g.w) continue;
             const int bd = (int)(pk_res[pass] & 0xffffu), bc = (int)(pk_res[pass] >> 16);
-            const int T = (int)uniq_threshold((uint32_t)bc, uniq);
+            const int T = (int)thr_res[pass];
             const uint16_t *srow = s_lds + xl * DP;
             const int l = bd > 0 ? srow[bd - 1] : 0x7fff, r = bd < D - 1 ? srow[bd + 1] : 0x7fff;
             const int tot_nbr = max(T - bc, 0) + max(T - l, 0) + max(T - r, 0);
@@ -1256,14 +1259,14 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     }
 }
 
-void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, float uniq,
+void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
 #ifdef CART_EXPERIMENTS
     if (const char *e = std::getenv("CART_WTA_DYNLDS")) lds += std::strtoul(e, nullptr, 0);   // residency experiments (unused LDS)
 #endif
-    WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, uniq, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
+    WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, thr, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
     switch (g.D) {
         case 64: hipLaunchKernelGGL((wta_kernel<4, false>), grid, block, lds, s, a); break;
         case 128: hipLaunchKernelGGL((wta_kernel<8, false>), grid, block, lds, s, a); break;
@@ -1273,10 +1276,10 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 
 // plan PAIRS: slabs 0 / 1 = pair sums {down, down-right} / {up, up-right}, slabs 2, 3, 5, 6 = right, left, down-left, up-left
 void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
-                      const Geometry &g, float uniq, int n_frames, hipStream_t s) {
+                      const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
-    WtaArgs a{slabs, cen_l, cen_r, wta_l, right_pk, g, uniq, 6, {0, 1, 2, 3, 5, 6, 0, 0}};
+    WtaArgs a{slabs, cen_l, cen_r, wta_l, right_pk, g, thr, 6, {0, 1, 2, 3, 5, 6, 0, 0}};
     switch (g.D) {
         case 64: hipLaunchKernelGGL((wta_kernel<4, true>), grid, block, lds, s, a); break;
         case 128: hipLaunchKernelGGL((wta_kernel<8, true>), grid, block, lds, s, a); break;
@@ -1329,7 +1332,7 @@ struct FusedArgs {
     uint16_t *wta_l;
     uint32_t *partial;   // [frame][block][sweep step][rv_row_slots] u16 right-view minima of every block (rv_key16; last slot of a row: unused sink)
     Geometry g;
-    float uniq;
+    const uint16_t *thr; // as WtaArgs::thr
     int xcd_frames;      // xcd_placement(): blocks are decoded per XCD
 };
 constexpr int kUpPath = 1;   // slab index of the direction computed here and never stored (oracle order: down, up, ...)
@@ -1378,7 +1381,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
 
     for (int i = threadIdx.x; i < RB * NRP; i += NT) (&s_rmin[0][0])[i] = 0xffffffffu;
-    for (int i = threadIdx.x; i < NTHR; i += NT) s_thr[i] = (uint16_t)uniq_threshold((uint32_t)i, a.uniq);
+    for (int i = threadIdx.x; i < NTHR; i += NT) s_thr[i] = a.thr[i];
 
     // right-census window of the wave (see aggregate_kernel): cooperative load offsets + this lane's read slots
     WinLane<LPP> wlane;
@@ -1647,8 +1650,8 @@ size_t wta_fused_partial_elems(const Geometry &g) {
 }
 
 void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
-                      uint32_t *partial, const Geometry &g, float uniq, int n_frames, hipStream_t s) {
-    FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, uniq, xcd_placement(g, n_frames) ? 1 : 0};
+                      uint32_t *partial, const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s) {
+    FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, thr, xcd_placement(g, n_frames) ? 1 : 0};
     const int wpb = fused_waves_for(g), cols = wpb * (64 / (g.D / 16));
     const int nblk = (g.w + cols - 1) / cols;
     dim3 grid(nblk * n_frames), block(64 * wpb);
