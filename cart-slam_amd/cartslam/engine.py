@@ -84,6 +84,11 @@ class Engine:
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN, code), "cart_engine_set_option")
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN_MIN_FRAMES, int(min_frames)), "cart_engine_set_option")
 
+    def set_spec_variants(self, s8_zero_invalid=False, s7_replicate_border=False):
+        """The two post-SGM choices that are open upstream (oracle S8 / S7 NOTEs); default: the oracle's spec."""
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_SPEC_S8_ZERO_INVALID, 1 if s8_zero_invalid else 0), "cart_engine_set_option")
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_SPEC_S7_REPLICATE_BORDER, 1 if s7_replicate_border else 0), "cart_engine_set_option")
+
     def set_chunk_frames(self, n):
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_CHUNK_FRAMES, int(n)), "cart_engine_set_option")
 

@@ -82,6 +82,7 @@ struct cart_engine {
     int auto_fused_min_frames = 1 << 30; // CART_OPT_PLAN = auto: launches of at least this many frames take the fused WTA
     int opt_plan = CART_PLAN_AUTO;       // cart_engine_set_option
     int opt_plan_min_frames = 1;         // with a forced plan: launches of fewer frames still take CART_PLAN_SLABS
+    int opt_spec = 0;                    // CART_OPT_SPEC_* bits: upstream variants of S8 / S7 (default: the oracle's spec)
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Slot> slots;
@@ -205,8 +206,9 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
 struct Options {
     int plan, plan_min_frames, chunk_frames;
     bool timing;
+    int spec;
 };
-Options snapshot_options(const cart_engine *e) { return Options{e->opt_plan, e->opt_plan_min_frames, e->chunk_frames, e->timing}; }   // caller holds e->mu
+Options snapshot_options(const cart_engine *e) { return Options{e->opt_plan, e->opt_plan_min_frames, e->chunk_frames, e->timing, e->opt_spec}; }   // caller holds e->mu
 
 // The launch plan of `n` frames handed to one launch sequence (include/cart_engine.h, CART_PLAN_*).
 int plan_for(const cart_engine *e, const Options &o, int n) {
@@ -384,6 +386,13 @@ int cart_engine_set_option(cart_engine *e, int option, int value) {
             if (value < 1 || value > 64) return fail("chunk frames must be in [1, 64]");  // pointer-table (multi) calls stay at kLaunchFrames
             e->chunk_frames = value;
             return 0;
+        case CART_OPT_SPEC_S8_ZERO_INVALID:
+        case CART_OPT_SPEC_S7_REPLICATE_BORDER: {
+            if (value != 0 && value != 1) return fail("spec variants are 0 or 1");
+            const int bit = option == CART_OPT_SPEC_S8_ZERO_INVALID ? 1 : 2;
+            e->opt_spec = value ? (e->opt_spec | bit) : (e->opt_spec & ~bit);
+            return 0;
+        }
         default: return fail("unknown option");
     }
 }
@@ -395,6 +404,8 @@ int cart_engine_get_option(cart_engine *e, int option, int *value) {
         case CART_OPT_PLAN: *value = e->opt_plan; return 0;
         case CART_OPT_PLAN_MIN_FRAMES: *value = e->opt_plan_min_frames; return 0;
         case CART_OPT_CHUNK_FRAMES: *value = e->chunk_frames; return 0;
+        case CART_OPT_SPEC_S8_ZERO_INVALID: *value = (e->opt_spec & 1) ? 1 : 0; return 0;
+        case CART_OPT_SPEC_S7_REPLICATE_BORDER: *value = (e->opt_spec & 2) ? 1 : 0; return 0;
         default: return fail("unknown option");
     }
 }
@@ -579,9 +590,9 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, st);
         STAGE("post");
         if (!smooth) {
-            launch_post(wl, rpk, gl, o, g, n, st);
+            launch_post(wl, rpk, gl, o, g, n, st, opt.spec);
         } else {
-            launch_post(wl, rpk, gl, strided_out(ta, tight_step, tight_fs), g, n, st);
+            launch_post(wl, rpk, gl, strided_out(ta, tight_step, tight_fs), g, n, st, opt.spec);
             STAGE("interpolate");
             // disparity.hpp:27-28: minDisparity = cfg*16, maxDisparity = image width (not x16)
             const int min16 = e->params.min_disparity * 16, maxd = g.w;

@@ -99,7 +99,8 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_
                       uint32_t *partial, const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
 void launch_uniq_table(float u, uint16_t *out_dev, hipStream_t s);   // test access to the integer uniqueness threshold
 void uniq_table_host(float u, uint16_t *out);
-void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames, hipStream_t s);
+void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames, hipStream_t s,
+                 int spec = 0);   // spec: CART_OPT_SPEC_* bits (1 = S8 zero-disparity-invalid, 2 = S7 replicated border)
 
 // ---- launchers (post_kernels.hip) ----
 void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, const OutBatch &dst, int w, int h, int radius,

@@ -1696,20 +1696,39 @@ __device__ __forceinline__ uint32_t median_cols(const SortedCol &c0, const Sorte
     return med3u(max(max(c0.lo, c1.lo), c2.lo), med3u(c0.mid, c1.mid, c2.mid), min(min(c0.hi, c1.hi), c2.hi));
 }
 
-// S7 median of the packed right view (low 16 bits) at (x, y); the image border keeps its own value
-__device__ __forceinline__ uint32_t right_median_at(const uint32_t *img, int x, int y, int w, int h) {
+// S7 median of the packed right view (low 16 bits) at (x, y); the image border keeps its own value -- or, with the S7 variant
+// (CART_OPT_SPEC_S7_REPLICATE_BORDER), is filtered over the replicated border like every other pixel
+__device__ __forceinline__ uint32_t right_median_at(const uint32_t *img, int x, int y, int w, int h, bool replicate) {
     const uint32_t *p = img + (size_t)y * w + x;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return p[0] & 0xffffu;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) {
+        if (!replicate) return p[0] & 0xffffu;
+        SortedCol c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t *q = img + min(max(x + k - 1, 0), w - 1);
+            c[k] = sort_col(q[(size_t)max(y - 1, 0) * w] & 0xffffu, q[(size_t)y * w] & 0xffffu, q[(size_t)min(y + 1, h - 1) * w] & 0xffffu);
+        }
+        return median_cols(c[0], c[1], c[2]);
+    }
     SortedCol c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = sort_col(p[k - 1 - w] & 0xffffu, p[k - 1] & 0xffffu, p[k - 1 + w] & 0xffffu);
     return median_cols(c[0], c[1], c[2]);
 }
 
-// S7 median of the left WTA map at (x, y); the image border keeps its own value
-__device__ __forceinline__ uint32_t left_median_at(const uint16_t *img, int x, int y, int w, int h) {
+// S7 median of the left WTA map at (x, y); border as above
+__device__ __forceinline__ uint32_t left_median_at(const uint16_t *img, int x, int y, int w, int h, bool replicate) {
     const uint16_t *p = img + (size_t)y * w + x;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return p[0];
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) {
+        if (!replicate) return p[0];
+        SortedCol c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint16_t *q = img + min(max(x + k - 1, 0), w - 1);
+            c[k] = sort_col(q[(size_t)max(y - 1, 0) * w], q[(size_t)y * w], q[(size_t)min(y + 1, h - 1) * w]);
+        }
+        return median_cols(c[0], c[1], c[2]);
+    }
     SortedCol c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = sort_col(p[k - 1 - w], p[k - 1], p[k - 1 + w]);
@@ -1718,19 +1737,21 @@ __device__ __forceinline__ uint32_t left_median_at(const uint16_t *img, int x, i
 
 // One pixel per thread: the right-view median is a gather at x - d, so the launch wants as many independent threads as
 // it can get (four pixels per thread with shared left columns measured 50 % slower).
+// spec: bit 0 = S8 variant (integer disparity 0 is invalid too), bit 1 = S7 variant (replicated-border medians); 0 = oracle S7 / S8
 __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const uint32_t *right_pk,
-                                                   const uint8_t *gray_l, OutBatch out, Geometry g) {
+                                                   const uint8_t *gray_l, OutBatch out, Geometry g, int spec) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
     if (x >= g.w || y >= g.h) return;
     const uint16_t *wl = wta_l + (size_t)frame * g.npx;
     const uint32_t *rp = right_pk + (size_t)frame * g.npx;
-    const uint32_t ml = left_median_at(wl, x, y, g.w, g.h);
-    bool invalid = gray_l[(size_t)frame * g.npx + (size_t)y * g.w + x] == 0 || ml == kWtaInvalid;
+    const bool replicate = (spec & 2) != 0;
+    const uint32_t ml = left_median_at(wl, x, y, g.w, g.h, replicate);
+    bool invalid = gray_l[(size_t)frame * g.npx + (size_t)y * g.w + x] == 0 || ml == kWtaInvalid || ((spec & 1) && (ml >> 4) == 0);
     if (!invalid) {
         const int d = (int)(ml >> 4);
         const int k = x - d;
         if (k >= 0 && k < g.w) {
-            const int mr = (int)right_median_at(rp, k, y, g.w, g.h);
+            const int mr = (int)right_median_at(rp, k, y, g.w, g.h, replicate);
             if (abs(mr - d) > 1) invalid = true;
         }
     }
@@ -1740,9 +1761,9 @@ __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const 
 }
 
 void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g,
-                 int n_frames, hipStream_t s) {
+                 int n_frames, hipStream_t s, int spec) {
     dim3 grid((g.w + 63) / 64, (g.h + 3) / 4, n_frames), block(64, 4);
-    hipLaunchKernelGGL(post_kernel, grid, block, 0, s, wta_l, right_pk, gray_l, out, g);
+    hipLaunchKernelGGL(post_kernel, grid, block, 0, s, wta_l, right_pk, gray_l, out, g, spec);
 }
 
 }  // namespace cart_amd

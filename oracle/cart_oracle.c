@@ -174,24 +174,36 @@ static int cmp_u16(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
-void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst) {
+void cart_oracle_median3x3_u16_ex(const uint16_t *src, int w, int h, uint16_t *dst, int variants) {
+    const int replicate = (variants & CART_ORACLE_VARIANT_S7_REPLICATE_BORDER) != 0;
 #pragma omp parallel for schedule(static)   /* rows are independent: same values in any order */
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) {
+            if (!replicate && (x < 1 || x >= w - 1 || y < 1 || y >= h - 1)) {
                 dst[(size_t)y * w + x] = src[(size_t)y * w + x];
                 continue;
             }
             uint16_t buf[9];
-            for (int i = 0; i < 9; i++) buf[i] = src[(size_t)(y - 1 + i / 3) * w + (x - 1 + i % 3)];
+            for (int i = 0; i < 9; i++) {
+                int yy = y - 1 + i / 3, xx = x - 1 + i % 3;   /* S7 variant: the window reads the replicated border */
+                yy = yy < 0 ? 0 : yy >= h ? h - 1 : yy;
+                xx = xx < 0 ? 0 : xx >= w ? w - 1 : xx;
+                buf[i] = src[(size_t)yy * w + xx];
+            }
             qsort(buf, 9, sizeof(uint16_t), cmp_u16);
             dst[(size_t)y * w + x] = buf[4];
         }
 }
+void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst) { cart_oracle_median3x3_u16_ex(src, w, h, dst, 0); }
 
 /* -------------------------------------------------------- S8 + S9 LR/range */
 void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
                                 int w, int h, int min_disp, int16_t *out) {
+    cart_oracle_lr_check_range_ex(left_med, right_med, gray_left, w, h, min_disp, out, 0);
+}
+void cart_oracle_lr_check_range_ex(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
+                                   int w, int h, int min_disp, int16_t *out, int variants) {
+    const int zero_invalid = (variants & CART_ORACLE_VARIANT_S8_ZERO_INVALID) != 0;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -199,6 +211,7 @@ void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_
             uint16_t org = left_med[i];
             int invalid = 0;
             if (gray_left[i] == 0 || org == CART_ORACLE_WTA_INVALID) invalid = 1;
+            else if (zero_invalid && (org >> 4) == 0) invalid = 1;   /* S8 variant: `d <= 0` on the integer disparity */
             else {
                 int d = (int)org >> 4;
                 int k = x - d;
@@ -215,6 +228,10 @@ void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_
 /* --------------------------------------------------------------- full SGM */
 int cart_oracle_sgm(const cart_oracle_sgm_params *p, const uint8_t *gray_l, const uint8_t *gray_r,
                     int16_t *disp, uint16_t *S_out) {
+    return cart_oracle_sgm_ex(p, gray_l, gray_r, disp, S_out, 0);
+}
+int cart_oracle_sgm_ex(const cart_oracle_sgm_params *p, const uint8_t *gray_l, const uint8_t *gray_r,
+                       int16_t *disp, uint16_t *S_out, int variants) {
     const int w = p->width, h = p->height, D = p->num_disparities;
     if (!(D == 64 || D == 128 || D == 256) || !(p->paths == 4 || p->paths == 8) || w <= 0 || h <= 0) return -1;
     if (p->p2 + 31 > 255) return -1;
@@ -236,9 +253,9 @@ int cart_oracle_sgm(const cart_oracle_sgm_params *p, const uint8_t *gray_l, cons
         for (long i = 0; i < (long)(npx * D); i++) S[i] = (uint16_t)(S[i] + L[i]);
     }
     cart_oracle_wta(S, w, h, D, p->uniqueness_ratio, wl, wr);
-    cart_oracle_median3x3_u16(wl, w, h, ml);
-    cart_oracle_median3x3_u16(wr, w, h, mr);
-    cart_oracle_lr_check_range(ml, mr, gray_l, w, h, p->min_disparity, disp);
+    cart_oracle_median3x3_u16_ex(wl, w, h, ml, variants);
+    cart_oracle_median3x3_u16_ex(wr, w, h, mr, variants);
+    cart_oracle_lr_check_range_ex(ml, mr, gray_l, w, h, p->min_disparity, disp, variants);
     free(cl); free(cr); free(L); if (!S_out) free(S);
     free(wl); free(wr); free(ml); free(mr);
     return 0;

@@ -72,7 +72,8 @@
  *                 465 750 on the 1242x375 scenes (tests/spec_variants.py).  One line to change in each place:
  *                 cart_oracle_lr_check_range (`gray_left[i] == 0 || org == CART_ORACLE_WTA_INVALID` -> add
  *                 `|| (org >> 4) == 0`) and post_kernel's `bool invalid =` line in sgm_kernels.hip.  tools/ref_pin produces the
- *                 reference outputs that decide it; tests/test_ref_pin.py names this variant when they disagree.
+ *                 reference outputs that decide it; tests/test_ref_pin.py names this variant when they disagree.  Both forms exist:
+ *                 CART_ORACLE_VARIANT_S8_ZERO_INVALID here, CART_OPT_SPEC_S8_ZERO_INVALID on the engine (likewise S7).
  *  S9 range     0xFFFF -> (min_disp-1)*16, else += min_disp*16; stored s16.
  *  S10 post stages: Jacobi reads of the unmodified input, out-of-image samples
  *                 skipped by window means and making a difference INVALID.
@@ -159,17 +160,27 @@ void cart_oracle_path_dir(int index, int *dx, int *dy);
 void cart_oracle_wta(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
                      uint16_t *left, uint16_t *right);
 
+/* The two post-stage choices that are open upstream (NOTEs at S7 / S8 above), selectable so that tests can hold BOTH forms
+ * against the engine (cart_engine_set_option CART_OPT_SPEC_*) until tools/ref_pin decides; 0 = the spec as written. */
+#define CART_ORACLE_VARIANT_S8_ZERO_INVALID 1      /* LR check also invalidates integer disparity 0 (`d <= 0`) */
+#define CART_ORACLE_VARIANT_S7_REPLICATE_BORDER 2  /* medians read a replicated border instead of passing it through */
+
 /* S7 */
 void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst);
+void cart_oracle_median3x3_u16_ex(const uint16_t *src, int w, int h, uint16_t *dst, int variants);
 
 /* S8+S9: left_med/right_med are the median-filtered WTA maps. */
 void cart_oracle_lr_check_range(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
                                 int w, int h, int min_disp, int16_t *out);
+void cart_oracle_lr_check_range_ex(const uint16_t *left_med, const uint16_t *right_med, const uint8_t *gray_left,
+                                   int w, int h, int min_disp, int16_t *out, int variants);
 
 /* Whole SGM core (a-4): gray L/R tight -> s16 disparity x16.  If S_out is
  * non-NULL it receives the summed volume [h][w][D] u16. Returns 0 / -1. */
 int cart_oracle_sgm(const cart_oracle_sgm_params *p, const uint8_t *gray_l, const uint8_t *gray_r,
                     int16_t *disp, uint16_t *S_out);
+int cart_oracle_sgm_ex(const cart_oracle_sgm_params *p, const uint8_t *gray_l, const uint8_t *gray_r,
+                       int16_t *disp, uint16_t *S_out, int variants);
 
 /* a-5 interpolation.cu:17-82 under S10; min_disp16 = cfg*16, max_disp = image width
  * (disparity.hpp:27-28 quirk). in/out tight s16; out may not alias in. */

@@ -44,6 +44,7 @@ def lib():
             build()
         _lib = C.CDLL(LIB)
         _lib.cart_oracle_sgm.restype = C.c_int
+        _lib.cart_oracle_sgm_ex.restype = C.c_int
         _lib.cart_oracle_find_peaks.restype = C.c_int
         _lib.cart_oracle_histogram_peak_params.restype = C.c_int
         _lib.cart_oracle_ccl.restype = C.c_int
@@ -96,29 +97,32 @@ def wta(S, uniqueness_ratio):
     return l, r
 
 
-def median3x3(a):
+VARIANT_S8_ZERO_INVALID, VARIANT_S7_REPLICATE_BORDER = 1, 2   # CART_ORACLE_VARIANT_* (the two choices that are open upstream)
+
+
+def median3x3(a, variants=0):
     h, w = a.shape
     a = np.ascontiguousarray(a, np.uint16)
     o = np.empty_like(a)
-    lib().cart_oracle_median3x3_u16(_p(a), w, h, _p(o))
+    lib().cart_oracle_median3x3_u16_ex(_p(a), w, h, _p(o), int(variants))
     return o
 
 
-def lr_check_range(lm, rm, gray, min_disp):
+def lr_check_range(lm, rm, gray, min_disp, variants=0):
     h, w = lm.shape
     o = np.empty((h, w), np.int16)
-    lib().cart_oracle_lr_check_range(_p(np.ascontiguousarray(lm, np.uint16)), _p(np.ascontiguousarray(rm, np.uint16)),
-                                     _p(np.ascontiguousarray(gray, np.uint8)), w, h, min_disp, _p(o))
+    lib().cart_oracle_lr_check_range_ex(_p(np.ascontiguousarray(lm, np.uint16)), _p(np.ascontiguousarray(rm, np.uint16)),
+                                        _p(np.ascontiguousarray(gray, np.uint8)), w, h, min_disp, _p(o), int(variants))
     return o
 
 
-def sgm(gl, gr, D, paths, min_disp=4, p1=10, p2=120, uniq=12, want_S=False):
+def sgm(gl, gr, D, paths, min_disp=4, p1=10, p2=120, uniq=12, want_S=False, variants=0):
     h, w = gl.shape
     p = SgmParams(w, h, min_disp, D, paths, p1, p2, uniq)
     disp = np.empty((h, w), np.int16)
     S = np.empty((h, w, D), np.uint16) if want_S else None
-    rc = lib().cart_oracle_sgm(C.byref(p), _p(np.ascontiguousarray(gl, np.uint8)), _p(np.ascontiguousarray(gr, np.uint8)),
-                               _p(disp), _p(S) if want_S else None)
+    rc = lib().cart_oracle_sgm_ex(C.byref(p), _p(np.ascontiguousarray(gl, np.uint8)), _p(np.ascontiguousarray(gr, np.uint8)),
+                                  _p(disp), _p(S) if want_S else None, int(variants))
     assert rc == 0, "cart_oracle_sgm failed"
     return (disp, S) if want_S else disp
 
@@ -130,11 +134,11 @@ def interpolate(disp, radius, iterations, min_disp16, max_disp):
     return o
 
 
-def disparity_module(left, right, D, paths, min_disp=4, p1=10, p2=120, uniq=12, radius=-1, iterations=5):
+def disparity_module(left, right, D, paths, min_disp=4, p1=10, p2=120, uniq=12, radius=-1, iterations=5, variants=0):
     """Whole ImageDisparityModule::runInternal (disparity.cu:49-80) on host arrays."""
     if left.ndim == 3:
         left, right = bgr2gray(left), bgr2gray(right)
-    d = sgm(left, right, D, paths, min_disp, p1, p2, uniq)
+    d = sgm(left, right, D, paths, min_disp, p1, p2, uniq, variants=variants)
     if radius > 0 and iterations > 0:
         d = interpolate(d, radius, iterations, min_disp * 16, left.shape[1])
     return d

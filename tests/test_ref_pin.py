@@ -29,14 +29,10 @@ def case_inputs(name):
 
 def explain(got, ref, l, r, md, D, P):
     """Which open upstream question (tools/ref_pin/README.md) would account for the difference."""
-    gl, gr = (O.bgr2gray(l), O.bgr2gray(r)) if l.ndim == 3 else (l, r)
-    _, S = O.sgm(gl, gr, D, P, md, want_S=True)
-    wl, wr = O.wta(S, 12)
-    ml, mr = O.median3x3(wl), O.median3x3(wr)
-    s8 = O.lr_check_range(ml, mr, gl, md).copy()
-    s8[(s8 != (md - 1) * 16) & ((ml >> 4) == 0)] = (md - 1) * 16
-    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; with S8's `d <= 0` variant "
-            f"{int((s8 != ref).sum())} would (tools/ref_pin/README.md lists the one-line changes)")
+    by_variant = {v: int((O.disparity_module(l, r, D, P, md, radius=-1, variants=v) != ref).sum()) for v in (1, 2, 3)}
+    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; with the S8 variant (`d <= 0` invalid) "
+            f"{by_variant[1]} would, with the S7 variant (replicated-border medians) {by_variant[2]}, with both {by_variant[3]} "
+            "(tools/ref_pin/README.md: both are switchable defaults)")
 
 
 @pytest.mark.skipif(not REF, reason="no reference outputs yet: run tools/ref_pin on a machine with OpenCV-CUDA")
