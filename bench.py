@@ -304,6 +304,24 @@ def run(args, world, rank, dev_index):
             del src, dst
         except Exception:
             copy_gbps = None
+    # Informational (never `value`): what ONE pair costs when nothing is batched -- the call a SLAM front end makes at camera
+    # rate: disparity + plane labelling + CCL of a single resident pair, host-synchronous, median of 30.
+    latency = None
+    if rank == 0:
+        lat_pipe = StereoPipeline(eng, provider="static", static_params=(6, 18, -5, 6, 11, 0), with_ccl=True, overlap=False)
+        l1, r1 = left[:1], right[:1]
+        for _ in range(5):
+            lat_pipe.process_batch(l1, r1)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(30):
+            t1 = time.perf_counter()
+            lat_pipe.process_batch(l1, r1)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ts.sort()
+        latency = {"ms": round(ts[len(ts) // 2] * 1e3, 4), "fastest_ms": round(ts[0] * 1e3, 4),
+                   "what": "one resident pair through disparity + plane labelling (static parameters) + CCL, enqueue to synchronize, median of 30"}
     pcie = None
     if world == 1 and not args.no_pcie:
         # Informational (never `value`): the same step when the caller hands over HOST buffers -- H2D of the 16 pairs
@@ -482,6 +500,8 @@ def run(args, world, rank, dev_index):
             out["value_pcie_inclusive"] = pcie["pairs_per_s"]   # the same step with the pair uploaded and disparity + planes downloaded
         if seq:
             out["sequence_mode"] = seq
+        if latency:
+            out["single_pair_latency"] = latency
         verified = None
         if world == 1 and not args.no_cpu_baseline:
             # the CPU leg: the oracle timed on the host cores; the same child also hands back the oracle's outputs of the first

@@ -126,6 +126,38 @@ def test_edge_inputs(torch_cuda):
     eng.close()
 
 
+@pytest.mark.parametrize("w,h,D,P", [(16384, 8, 64, 8), (16, 2000, 64, 4), (16, 8, 256, 8), (4099, 11, 128, 8)])
+def test_extreme_shapes(torch_cuda, w, h, D, P):
+    """The smallest and the most lopsided images the engine accepts (16 x 8 is its minimum, 16384 its widest): one W-step scan
+    per row group, 2000-step vertical scans on two lane groups, an image narrower than a sixteenth of its disparity range, and a
+    prime width -- single frame and a batch of three, every launch plan, through plane labelling and components."""
+    torch = torch_cuda
+    rng = np.random.default_rng(w * 31 + h)
+    base = rng.integers(0, 256, (h, w + 40)).astype(np.uint8)
+    l, r = np.ascontiguousarray(base[:, 20:20 + w]), np.ascontiguousarray(base[:, 27:27 + w])   # a 7-pixel shift: real matches where the width allows
+    exp = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=3)
+    for plan in ("slabs", "fused_up", "pairs"):
+        eng.set_plan(plan)
+        got = eng.compute_disparity(dev(torch, np.stack([l, l, l])), dev(torch, np.stack([r, r, r]))).cpu().numpy()
+        assert all((got[k] == exp).all() for k in range(3)), f"{plan}: {int((got[0] != exp).sum())} pixels differ"
+        assert (eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy() == exp).all(), plan
+    assert eng.device_status() == 0
+    hist = torch.zeros(256, dtype=torch.int32, device="cuda")
+    d = eng.compute_disparity(dev(torch, l), dev(torch, r))
+    pd = eng.plane_derivative_hist(d, hist)
+    eb, eh = O.plane_derivative(exp)
+    assert (pd.cpu().numpy() == eb).all() and (hist.cpu().numpy() == eh).all()
+    pp = (6, 18, -5, 6, 11, 0)
+    planes = eng.plane_classify(pd, pp)
+    ep = O.classify(eb, pp)
+    assert (planes.cpu().numpy() == ep).all()
+    ids, n = eng.plane_ccl(planes)
+    eids, en = O.ccl(ep)
+    assert (ids.cpu().numpy() == eids).all() and int(n.item()) == en
+    eng.close()
+
+
 def test_bad_arguments_fail_loudly(torch_cuda):
     torch = torch_cuda
     from cartslam import Engine, EngineError
