@@ -530,6 +530,8 @@ def run(args, world, rank, dev_index):
                 dist.destroy_process_group()
             sys.exit(4)
     if dist.is_initialized():
+        if world > 1:
+            dist.barrier()   # rank 0 has run its informational legs meanwhile: every rank leaves together, no communicator is torn down under a peer
         dist.destroy_process_group()
 
 
