@@ -11,7 +11,9 @@ frames, which are not available offline):
   "stripes"    a facade of exactly periodic vertical stripes, periods 8 / 16 / 24 px: repetitive texture, uniqueness rejections;
   "saturated"  a saturated (255) and a black (0) patch in the left image: gray == 0 is the LR check's mask (oracle S8);
   "pole"       a 1-px-wide and a 3-px-wide near pole in front of the ground plane: thin structures;
-  "wall"       a large textureless fronto-parallel wall.
+  "wall"       a large textureless fronto-parallel wall;
+  "photometric" the right camera sees the scene 12 % brighter with an offset and sensor noise of its own (clipped at 255):
+               what two real cameras do to each other, and what the census transform is there to absorb.
 """
 import numpy as np
 
@@ -59,7 +61,7 @@ def _texture(w, h, salt, xoff):
     return np.clip(np.rint(img), 1, 255).astype(np.uint8)  # never 0: gray==0 is the reference's LR-check mask
 
 
-SCENES = ("road", "stripes", "saturated", "pole", "wall")
+SCENES = ("road", "stripes", "saturated", "pole", "wall", "photometric")
 
 
 def _scene_regions(w, h, scene, frame):
@@ -149,7 +151,12 @@ def make_pair(w, h, D, min_disp=4, seed=DEFAULT_SEED, frame=0, channels=1, scene
     for c in range(channels):
         tex = _paint_scene(_texture(w, h, seed + 1000003 * c, 2 * frame), scene, w, h, frame)
         lefts.append(tex)
-        rights.append(np.take_along_axis(tex, src, axis=1))
+        right = np.take_along_axis(tex, src, axis=1)
+        if scene == "photometric":   # gain, offset and independent noise in the right camera
+            yy2, xx2 = np.meshgrid(np.arange(h, dtype=np.int64), np.arange(w, dtype=np.int64), indexing="ij")
+            noise = sum(_hash01(xx2 + 7 * frame, yy2, seed + 15485863 * (k + 1) + c) for k in range(4)) - 2.0   # ~N(0, 0.58)
+            right = np.clip(np.rint(right.astype(np.float64) * 1.12 + 6.0 + noise * (3.0 / 0.577)), 0, 255).astype(np.uint8)
+        rights.append(right)
     if channels == 1:
         return lefts[0], rights[0], gt
     return np.stack(lefts, axis=-1), np.stack(rights, axis=-1), gt

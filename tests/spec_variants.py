@@ -53,7 +53,7 @@ def main():
         rows.append((os.path.basename(f),) + variants(l, r, int(z["D"]), int(z["P"]), int(z["min_disp"])))
     l, r, _ = synth.make_pair(1242, 375, 128, 4)
     rows.append(("synth 1242x375 D=128 P=8 (bench frame 0)",) + variants(l, r, 128, 8, 4))
-    for scene in ("stripes", "saturated", "pole", "wall"):
+    for scene in ("stripes", "saturated", "pole", "wall", "photometric"):
         l, r, _ = synth.make_pair(1242, 375, 128, 4, scene=scene)
         rows.append((f"synth 1242x375 D=128 P=8 scene={scene}",) + variants(l, r, 128, 8, 4))
     print(f"{'scene':52s} {'S8: d<=0 also invalid':>22s} {'S7: replicated border':>22s} {'valid':>9s} {'pixels':>9s}")

@@ -332,11 +332,12 @@ def test_full_size_against_oracle(torch_cuda, w, h, D, P):
     eng.close()
 
 
-@pytest.mark.parametrize("scene", ["stripes", "saturated", "pole", "wall"])
+@pytest.mark.parametrize("scene", ["stripes", "saturated", "pole", "wall", "photometric"])
 def test_full_size_scene_content_against_oracle(torch_cuda, scene):
     """The headline configuration (1242x375, D=128, 8 paths) on scenes with the content street images have and value noise
     does not -- an exactly periodic striped facade (equal-cost candidates every 8 / 16 / 24 px), a saturated and a BLACK
-    patch (gray == 0 is the LR check's mask, oracle S8), 1-px / 3-px poles, a large textureless wall -- whole frame through
+    patch (gray == 0 is the LR check's mask, oracle S8), 1-px / 3-px poles, a large textureless wall, a right camera with its
+    own gain, offset and noise -- whole frame through
     classification, components and the component table, every launch plan, bit-exact.  (No KITTI data is available offline;
     this is the nearest substitute.)"""
     torch = torch_cuda
