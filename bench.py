@@ -68,6 +68,9 @@ for f, params in verify.items():
     keep["disp_" + f], keep["planes_" + f] = d, O.classify(dd, tuple(params))
 if verify_path:
     np.savez(verify_path, **keep)
+if budget < 0:      # verification only (multi-rank runs: the CPU baseline itself is timed at N = 1 only)
+    print(json.dumps({"verify_only": True}))
+    sys.exit(0)
 l, r, _ = synth.make_pair(w, h, D, 4)
 one(l, r); one(l, r)
 times, t_all = [], time.perf_counter()
@@ -116,6 +119,8 @@ def cpu_baseline(w, h, D, P, seconds_budget=12.0, verify_path="", verify=None):
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline child failed: " + r.stderr[-2000:])
     t = json.loads(r.stdout.strip().splitlines()[-1])
+    if t.get("verify_only"):
+        return None
     return {"value": round(1.0 / t["median_s"], 4), "unit": "stereo-pairs/sec", "cores": cores, "kind": "port",
             "spread": {"fastest": round(1.0 / t["min_s"], 4), "slowest": round(1.0 / t["max_s"], 4), "repetitions": t["reps"]},
             "sample": f"median of {t['reps']} repetitions of 1 pair {w}x{h} D={D} {P} paths + plane labelling + CCL; OpenMP oracle "
@@ -503,13 +508,17 @@ def run(args, world, rank, dev_index):
         if latency:
             out["single_pair_latency"] = latency
         verified = None
-        if world == 1 and not args.no_cpu_baseline:
-            # the CPU leg: the oracle timed on the host cores; the same child also hands back the oracle's outputs of the first
-            # and the last frame of the batch, against which the LAST TIMED STEP's outputs are compared (outside every timed region)
+        if not args.no_cpu_baseline:
+            # the CPU leg: the oracle timed on the host cores (N = 1 only); the same child also hands back the oracle's outputs of
+            # the first and the last frame of rank 0's batch, against which the LAST TIMED STEP's outputs are compared (outside
+            # every timed region; with more than one rank the child only verifies)
             import tempfile
             with tempfile.TemporaryDirectory() as td:
                 vp = os.path.join(td, "verify.npz")
-                out["cpu_baseline"] = cpu_baseline(w, h, D, P, verify_path=vp, verify={first_frame + k: got[k]["params"] for k in check_frames})
+                cb = cpu_baseline(w, h, D, P, seconds_budget=12.0 if world == 1 else -1.0, verify_path=vp,
+                                  verify={first_frame + k: got[k]["params"] for k in check_frames})
+                if cb is not None:
+                    out["cpu_baseline"] = cb
                 z = np.load(vp)
                 bad = []
                 for k in check_frames:
@@ -521,7 +530,7 @@ def run(args, world, rank, dev_index):
                 verified = not bad
                 out["verification"] = {"frames": check_frames, "of": "the last timed step", "against": "oracle (cpu_baseline child): disparity bit-exact, "
                                        "plane labels bit-exact under the parameters the run used", "mismatches": bad}
-        out["verified"] = verified   # None: not checked (multi-rank runs and --no-cpu-baseline have no CPU leg)
+        out["verified"] = verified   # None: not checked (--no-cpu-baseline)
         sys.stdout.flush()
         os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
         if verified is False:

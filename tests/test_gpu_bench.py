@@ -45,12 +45,12 @@ def test_two_ranks_through_the_drivers_launch_form():
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allow-shared-gpu", "--sequence", "--no-cpu-baseline"] + SMALL
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--allow-shared-gpu", "--sequence"] + SMALL
     pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
     d = one_json_line(pr.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_pairs_per_step"] == 8 and d["config"]["world_size"] == 2
-    assert d["scaling"] == "weak" and d["verified"] is None and "cpu_baseline" not in d
+    assert d["scaling"] == "weak" and d["verified"] is True and "cpu_baseline" not in d   # rank 0's outputs are checked, the CPU baseline is an N = 1 figure
     assert d["sequence_mode"]["frames"] == 8 and d["sequence_mode"]["pairs_per_s"] > 0
 
 
