@@ -435,8 +435,8 @@ def run(args, world, rank, dev_index):
             tj = json.load(open(tf))
         except Exception:
             tj = {}
-        def measured_traffic(kernel):   # HBM bytes per launch from the committed PMC passes of THIS configuration, else None
-            return tj.get(f"{kernel}_{w}x{h}_D{D}_P{P}_B{fpl}{suffix}", {}).get("hbm_bytes_per_launch")
+        def measured_traffic(kernel, field="hbm_bytes_per_launch"):   # per launch, from the committed PMC passes of THIS configuration, else None
+            return tj.get(f"{kernel}_{w}x{h}_D{D}_P{P}_B{fpl}{suffix}", {}).get(field)
         wta_ms = stages.get("wta", 0.0)
         # every aggregation launch of one launch sequence (plan "pairs": two pair sweeps + the 4-direction launch)
         agg_ms = sum(stages.get(k, 0.0) for k in ("aggregate", "pair_down", "pair_up"))
@@ -493,6 +493,16 @@ def run(args, world, rank, dev_index):
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
         }
+        vi = measured_traffic("aggregate", "valu_insts_per_launch")
+        if vi and agg_ms > 0 and not fused:
+            # The aggregation launch is bound by VALU issue, not by HBM: its stored instruction count (SQ_INSTS_VALU of the
+            # committed PMC pass) x 4 cycles per wave64 instruction over 1024 SIMDs, against this run's launch time.  `frac` uses the chip's
+            # 2.4 GHz maximum clock; under this load the chip holds ~1.97 GHz, at which the same figure is `frac_at_held_clock`.
+            issue = vi * 4.0 / 1024.0 / (agg_ms * 1e-3)
+            out["roofline_valu_issue"] = {"bound": "valu-issue (informational)", "kernel": "aggregate_kernel", "valu_insts_per_launch": vi,
+                                          "source": "profiles/traffic.json (stored SQ_INSTS_VALU of this configuration)",
+                                          "achieved_GHz_equivalent": round(issue / 1e9, 3), "peak_GHz": 2.4, "frac": round(issue / 2.4e9, 4),
+                                          "frac_at_held_clock": round(issue / 1.97e9, 4)}
         if wta_ms > 0 and not fused:
             # the second kernel of the path, same accounting (PD + 4 bytes per pixel), HBM-read bound
             wta_bytes = alg_bytes_wta(w, h, D, P) * fpl
