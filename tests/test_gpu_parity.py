@@ -384,6 +384,24 @@ def test_full_size_scene_content_against_oracle(torch_cuda, scene):
     eng.close()
 
 
+@pytest.mark.parametrize("w,h", [(1241, 376), (1226, 370), (1224, 370)])
+def test_native_kitti_frame_sizes(torch_cuda, w, h):
+    """The other frame sizes KITTI sequences come in (odometry 00-02: 1241x376, 03: 1242x375, 04-10: 1226x370; raw drives
+    1224x370): the reference resizes to its configured size, but an engine configured for the native size must be just as
+    exact -- D=128, 8 paths, every launch plan, a batch of two (the widths are odd or leave ragged tiles everywhere)."""
+    torch = torch_cuda
+    D, P = 128, 8
+    l, r, _ = synth.make_pair(w, h, D, 4, seed=w * 7 + h, scene="pole")
+    exp = O.disparity_module(l, r, D, P, 4, radius=2, iterations=1)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2)
+    for plan in ("slabs", "fused_up", "pairs"):
+        eng.set_plan(plan)
+        got = eng.compute_disparity(dev(torch, np.stack([l, l])), dev(torch, np.stack([r, r]))).cpu().numpy()
+        assert (got[0] == exp).all() and (got[1] == exp).all(), f"{plan}: {int((got[0] != exp).sum())} pixels differ"
+    assert eng.device_status() == 0
+    eng.close()
+
+
 def test_full_size_properties_1080p_d256(torch_cuda):
     """BASELINE config 4 (1920x1080, D=256, 8 paths): too slow for a full oracle run in a test, so
     size-independent properties: slab bounds, path starts equal the matching cost, batch == single,
