@@ -426,4 +426,8 @@ class StereoPipeline:
         if self.with_ccl and n:
             out["ids"], out["n_components"] = eng.plane_ccl(planes)
             out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
+        elif self.with_ccl:   # a rank without frames still hands every key to the gather
+            out["ids"] = torch.empty((0, eng.height, eng.width), dtype=torch.int32, device=dev)
+            out["n_components"] = torch.empty((0,), dtype=torch.int32, device=dev)
+            out["components"] = torch.empty((0, self.max_components, 7), dtype=torch.int32, device=dev)
         return out

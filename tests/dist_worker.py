@@ -77,13 +77,15 @@ def main():
             if rank == 0:
                 ls, rs = frames_of(range(next_id, next_id + n), w, h, D, 4321)
                 sl, sr = torch.from_numpy(ls).cuda(), torch.from_numpy(rs).cuda()
-            handles.append(pipe.submit_sequence(sl, sr, n))
+            handles.append(pipe.submit_sequence(sl, sr, n, keys=("disparity", "planes", "ids", "n_components")))
             next_id += n
         for k, hd in enumerate(handles):
             got = hd.result()
             if rank == 0:
                 res[f"pseq{k}_disp"] = got["disparity"].cpu().numpy()
                 res[f"pseq{k}_planes"] = got["planes"].cpu().numpy()
+                res[f"pseq{k}_ids"] = got["ids"].cpu().numpy()
+                res[f"pseq{k}_ncomp"] = got["n_components"].cpu().numpy()
             else:
                 assert got["disparity"] is None and got["planes"] is None
         np.savez(out_path, **res)

@@ -138,6 +138,7 @@ def test_two_ranks_real_engine_equal_single_process(tmp_path, device_schedule):
                 assert z[f"pseq{q}_disp"].shape[0] == size
                 assert (z[f"pseq{q}_disp"][k] == d1).all(), f"pipelined sequence {q} disparity frame {fid}"
                 assert (z[f"pseq{q}_planes"][k] == p1).all(), f"pipelined sequence {q} planes frame {fid}"
+                assert (z[f"pseq{q}_ids"][k] == o["ids"][k].cpu().numpy()).all() and int(z[f"pseq{q}_ncomp"][k]) == int(o["n_components"][k].item()), f"pipelined sequence {q} components frame {fid}"
             seen += 1
     assert seen == total
     assert "seq_disp" not in ranks[1].files
