@@ -34,7 +34,7 @@ class LaunchPlan(C.Structure):
 
 PLAN_AUTO, PLAN_SLABS, PLAN_FUSED_UP, PLAN_PAIRS = -1, 0, 1, 2      # CART_PLAN_*
 OPT_PLAN, OPT_PLAN_MIN_FRAMES, OPT_CHUNK_FRAMES = 0, 1, 2           # CART_OPT_*
-OPT_SPEC_S8_ZERO_INVALID, OPT_SPEC_S7_REPLICATE_BORDER = 3, 4       # CART_OPT_SPEC_*: upstream variants of oracle S8 / S7
+OPT_SPEC_S8_ZERO_INVALID, OPT_SPEC_S7_REPLICATE_BORDER, OPT_SPEC_S5_TOP2 = 3, 4, 5   # CART_OPT_SPEC_*: upstream variants of oracle S8 / S7 / S5
 
 
 class SuperpixelParams(C.Structure):

@@ -84,8 +84,9 @@ class Engine:
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN, code), "cart_engine_set_option")
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN_MIN_FRAMES, int(min_frames)), "cart_engine_set_option")
 
-    def set_spec_variants(self, s8_zero_invalid=False, s7_replicate_border=False):
-        """The two post-SGM choices that are open upstream (oracle S8 / S7 NOTEs); default: the oracle's spec."""
+    def set_spec_variants(self, s8_zero_invalid=False, s7_replicate_border=False, s5_top2=False):
+        """The three choices that are open upstream (oracle S8 / S7 / S5 NOTEs); default: the oracle's spec."""
+        self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_SPEC_S5_TOP2, 1 if s5_top2 else 0), "cart_engine_set_option")
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_SPEC_S8_ZERO_INVALID, 1 if s8_zero_invalid else 0), "cart_engine_set_option")
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_SPEC_S7_REPLICATE_BORDER, 1 if s7_replicate_border else 0), "cart_engine_set_option")
 

@@ -212,6 +212,7 @@ Options snapshot_options(const cart_engine *e) { return Options{e->opt_plan, e->
 
 // The launch plan of `n` frames handed to one launch sequence (include/cart_engine.h, CART_PLAN_*).
 int plan_for(const cart_engine *e, const Options &o, int n) {
+    if (o.spec & 4) return CART_PLAN_SLABS;   // the S5 variant exists in the two-kernel WTA only
     if (o.plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
     if (n < o.plan_min_frames) return CART_PLAN_SLABS;
     // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP.  So do
@@ -387,9 +388,10 @@ int cart_engine_set_option(cart_engine *e, int option, int value) {
             e->chunk_frames = value;
             return 0;
         case CART_OPT_SPEC_S8_ZERO_INVALID:
-        case CART_OPT_SPEC_S7_REPLICATE_BORDER: {
+        case CART_OPT_SPEC_S7_REPLICATE_BORDER:
+        case CART_OPT_SPEC_S5_TOP2: {
             if (value != 0 && value != 1) return fail("spec variants are 0 or 1");
-            const int bit = option == CART_OPT_SPEC_S8_ZERO_INVALID ? 1 : 2;
+            const int bit = option == CART_OPT_SPEC_S8_ZERO_INVALID ? 1 : option == CART_OPT_SPEC_S7_REPLICATE_BORDER ? 2 : 4;
             e->opt_spec = value ? (e->opt_spec | bit) : (e->opt_spec & ~bit);
             return 0;
         }
@@ -406,6 +408,7 @@ int cart_engine_get_option(cart_engine *e, int option, int *value) {
         case CART_OPT_CHUNK_FRAMES: *value = e->chunk_frames; return 0;
         case CART_OPT_SPEC_S8_ZERO_INVALID: *value = (e->opt_spec & 1) ? 1 : 0; return 0;
         case CART_OPT_SPEC_S7_REPLICATE_BORDER: *value = (e->opt_spec & 2) ? 1 : 0; return 0;
+        case CART_OPT_SPEC_S5_TOP2: *value = (e->opt_spec & 4) ? 1 : 0; return 0;
         default: return fail("unknown option");
     }
 }
@@ -587,7 +590,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         STAGE("wta");
         if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq_thr, n, st);
         else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, st);
-        else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, st);
+        else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, st, (opt.spec & 4) != 0);
         STAGE("post");
         if (!smooth) {
             launch_post(wl, rpk, gl, o, g, n, st, opt.spec);

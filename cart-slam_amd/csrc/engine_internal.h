@@ -81,7 +81,7 @@ int agg_residency_cap(int ndirs, int D, int n_frames);  // 4-wave aggregation wo
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 // thr = device table of the integer uniqueness threshold for every best cost 0..2047 (launch_uniq_table, built once per engine)
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
-                int n_frames, hipStream_t s);
+                int n_frames, hipStream_t s, bool top2 = false);   // top2: the S5 variant (second-best only), two-kernel WTA only
 // plan PAIRS (sgm_kernels.hip): one sweep per vertical direction carries that direction and the diagonal leaning the same way
 size_t pair_xch_elems(const Geometry &g);   // 8-byte words of the per-frame hand-over buffer
 void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,

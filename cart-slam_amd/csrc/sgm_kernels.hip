@@ -1103,7 +1103,13 @@ struct WtaArgs {
     int slab_idx[kMaxPaths];
 };
 
-template <int LPP, bool PAIRS>
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+// TOP2 = the S5 variant (CART_OPT_SPEC_S5_TOP2): uniqueness looks at the SECOND-best (cost, d) only -- the second-smallest
+// (cost << 16 | d) key of the pixel -- instead of at every disparity.
+template <int LPP, bool PAIRS, bool TOP2 = false>
 __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lds[];  // [kWtaTileX][DP]
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         __syncthreads();
     }
 
-    uint32_t pk_res[NPASS], tot_res[NPASS], thr_res[NPASS];
+    uint32_t pk_res[NPASS], tot_res[NPASS], thr_res[NPASS];   // TOP2: tot_res holds the pixel's second-smallest key
     constexpr bool PREFETCH = NPASS >= 4;
     v4u pf[PREFETCH ? 2 : 1][PREFETCH ? kMaxPaths : 1];
     auto issue_pass = [&](int pass, v4u (&dst)[PREFETCH ? kMaxPaths : 1]) {
@@ -1213,7 +1219,25 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
         m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
         uint32_t pk = ((m >> 4) << 16) | (uint32_t)(d0 + (int)(m & 15u));
-        pk = group_allmin<LPP>(pk);
+        uint32_t cand = 0;
+        if constexpr (TOP2) {
+            // the lane's two smallest 16-bit keys: a tournament on (min, second) pairs, both halves of the packed registers at once
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo[k] = pk_min(key[2 * k], key[2 * k + 1]); hi[k] = pk_max(key[2 * k], key[2 * k + 1]); }
+            const uint32_t m01 = pk_min(lo[0], lo[1]), s01 = pk_min(pk_max(lo[0], lo[1]), pk_min(hi[0], hi[1]));
+            const uint32_t m23 = pk_min(lo[2], lo[3]), s23 = pk_min(pk_max(lo[2], lo[3]), pk_min(hi[2], hi[3]));
+            const uint32_t mm4 = pk_min(m01, m23), ss4 = pk_min(pk_max(m01, m23), pk_min(s01, s23));
+            const uint32_t mL = mm4 & 0xffffu, mH = mm4 >> 16, sL = ss4 & 0xffffu, sH = ss4 >> 16;
+            const uint32_t second = min(max(mL, mH), min(sL, sH));   // (the smaller of mL, mH is `m` above)
+            const uint32_t second_full = ((second >> 4) << 16) | (uint32_t)(d0 + (int)(second & 15u));
+            const uint32_t best_all = group_allmin<LPP>(pk);
+            cand = pk == best_all ? second_full : pk;   // the lane that holds the pixel's best key offers its runner-up
+            pk = best_all;
+            cand = group_allmin<LPP>(cand);
+        } else {
+            pk = group_allmin<LPP>(pk);
+        }
         // = uniq_threshold(best cost): one load from the engine's 4 KB table (L1-resident) instead of the float search -- a
         // division and five multiply-compares, ~45 VALU instructions per lane and pass, twice (here and where the pixel's
         // first lane decides), about a quarter of this kernel's instructions; at D = 64 the kernel is as much VALU- as HBM-bound
@@ -1222,7 +1246,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
-        tot_res[pass] = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
+        tot_res[pass] = TOP2 ? cand : group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         pk_res[pass] = pk;
         thr_res[pass] = T;
     }
@@ -1239,7 +1263,9 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
             const int l = bd > 0 ? srow[bd - 1] : 0x7fff, r = bd < D - 1 ? srow[bd + 1] : 0x7fff;
             const int tot_nbr = max(T - bc, 0) + max(T - l, 0) + max(T - r, 0);
             uint32_t out = kWtaInvalid;
-            if ((int)tot_res[pass] == tot_nbr) {
+            // TOP2: unique iff the runner-up's cost reaches the threshold or it sits next to the winner
+            const bool unique = TOP2 ? ((int)(tot_res[pass] >> 16) >= T || abs((int)(tot_res[pass] & 0xffffu) - bd) <= 1) : (int)tot_res[pass] == tot_nbr;
+            if (unique) {
                 int subp = bd * 16;
                 if (bd > 0 && bd < D - 1) {
                     const int num = l - r, den = l - 2 * bc + r;
@@ -1260,13 +1286,21 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
 }
 
 void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
-                int n_frames, hipStream_t s) {
+                int n_frames, hipStream_t s, bool top2) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
 #ifdef CART_EXPERIMENTS
     if (const char *e = std::getenv("CART_WTA_DYNLDS")) lds += std::strtoul(e, nullptr, 0);   // residency experiments (unused LDS)
 #endif
     WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, thr, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
+    if (top2) {   // S5 variant (CART_OPT_SPEC_S5_TOP2)
+        switch (g.D) {
+            case 64: hipLaunchKernelGGL((wta_kernel<4, false, true>), grid, block, lds, s, a); break;
+            case 128: hipLaunchKernelGGL((wta_kernel<8, false, true>), grid, block, lds, s, a); break;
+            default: hipLaunchKernelGGL((wta_kernel<16, false, true>), grid, block, lds, s, a); break;
+        }
+        return;
+    }
     switch (g.D) {
         case 64: hipLaunchKernelGGL((wta_kernel<4, false>), grid, block, lds, s, a); break;
         case 128: hipLaunchKernelGGL((wta_kernel<8, false>), grid, block, lds, s, a); break;

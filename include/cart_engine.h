@@ -84,12 +84,14 @@ enum {
     CART_OPT_PLAN = 0,            /* CART_PLAN_*; default AUTO */
     CART_OPT_PLAN_MIN_FRAMES = 1, /* with a forced plan: launches of fewer frames take SLABS (default 1) */
     CART_OPT_CHUNK_FRAMES = 2,    /* frames per launch sequence inside one batched call (default 16, 1..64) */
-    /* The two post-SGM choices that are open upstream (cv::cuda::StereoSGM is un-vendored and un-versioned in the reference:
+    /* The three choices that are open upstream (cv::cuda::StereoSGM is un-vendored and un-versioned in the reference:
      * oracle/cart_oracle.h, NOTEs at S7 and S8).  Default 0 = the oracle's spec.  Whoever runs tools/ref_pin against the
      * reference's OpenCV flips the one that its outputs ask for; both forms are held bit-exact against the oracle's
      * variants by tests/test_gpu_parity.py::test_spec_variants.  These change results, by design; nothing else does. */
     CART_OPT_SPEC_S8_ZERO_INVALID = 3,      /* 1: the LR check also invalidates pixels whose integer disparity is 0 (older libSGM's `d <= 0`) */
-    CART_OPT_SPEC_S7_REPLICATE_BORDER = 4   /* 1: the 3x3 medians filter the one-pixel image border over a replicated border instead of passing it through */
+    CART_OPT_SPEC_S7_REPLICATE_BORDER = 4,  /* 1: the 3x3 medians filter the one-pixel image border over a replicated border instead of passing it through */
+    CART_OPT_SPEC_S5_TOP2 = 5               /* 1: uniqueness tests the second-best (cost, d) only -- the top-2 wording of SURVEY.md 8a-4(4) -- instead of every
+                                               disparity (the libSGM form, oracle S5); such an engine always takes plan SLABS */
 };
 int cart_engine_set_option(cart_engine *engine, int option, int value);
 int cart_engine_get_option(cart_engine *engine, int option, int *value);

@@ -125,6 +125,11 @@ void cart_oracle_path_dir(int index, int *dx, int *dy) {
 /* ----------------------------------------------------------- S5 + S6 WTA */
 void cart_oracle_wta(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
                      uint16_t *left, uint16_t *right) {
+    cart_oracle_wta_ex(S, w, h, D, uniqueness_ratio, left, right, 0);
+}
+void cart_oracle_wta_ex(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
+                        uint16_t *left, uint16_t *right, int variants) {
+    const int top2 = (variants & CART_ORACLE_VARIANT_S5_TOP2) != 0;
     const float u = (float)(100 - uniqueness_ratio) / 100.0f;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++) {
@@ -139,6 +144,20 @@ void cart_oracle_wta(const uint16_t *S, int w, int h, int D, int uniqueness_rati
             int bd = (int)(best & 0xffffu);
             uint32_t bc = best >> 16;
             int uniq = 1;
+            if (top2) {
+                /* S5 variant, the wording of SURVEY.md 8a-4(4): ONE pass over d that tracks the best and the second-best
+                 * (cost, d), both replaced on a strictly smaller cost only; only the second-best is tested */
+                uint32_t c1 = 0xffffffffu, c2 = 0xffffffffu;
+                int d1 = -1, d2 = -1;
+                for (int d = 0; d < D; d++) {
+                    if (s[d] < c1) { c2 = c1; d2 = d1; c1 = s[d]; d1 = d; }
+                    else if (s[d] < c2) { c2 = s[d]; d2 = d; }
+                }
+                if (d2 >= 0) {
+                    int dd = d2 - d1; if (dd < 0) dd = -dd;
+                    uniq = ((float)c2 * u >= (float)c1) || dd <= 1;
+                }
+            } else
             for (int d = 0; d < D; d++) {
                 float lhs = (float)s[d] * u; /* one rounded f32 multiply (-ffp-contract=off) */
                 int u1 = lhs >= (float)bc;
@@ -252,7 +271,7 @@ int cart_oracle_sgm_ex(const cart_oracle_sgm_params *p, const uint8_t *gray_l, c
 #pragma omp parallel for schedule(static)
         for (long i = 0; i < (long)(npx * D); i++) S[i] = (uint16_t)(S[i] + L[i]);
     }
-    cart_oracle_wta(S, w, h, D, p->uniqueness_ratio, wl, wr);
+    cart_oracle_wta_ex(S, w, h, D, p->uniqueness_ratio, wl, wr, variants);
     cart_oracle_median3x3_u16_ex(wl, w, h, ml, variants);
     cart_oracle_median3x3_u16_ex(wr, w, h, mr, variants);
     cart_oracle_lr_check_range_ex(ml, mr, gray_l, w, h, p->min_disparity, disp, variants);

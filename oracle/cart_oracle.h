@@ -49,8 +49,9 @@
  *                 text is a paraphrase, marked [EXTERNAL-UNVERIFIED] there.  Neither form
  *                 can be checked against the reference here (opencv_contrib is absent, no
  *                 fixtures): parity unpinned.  Should a reference-side fixture ever show
- *                 the top-2 form, this line and wta's uniqueness loop are the one place to
- *                 change.
+ *                 the top-2 form: it exists as CART_ORACLE_VARIANT_S5_TOP2 here and as
+ *                 CART_OPT_SPEC_S5_TOP2 on the engine (one pass over d tracking best and second-best
+ *                 (cost, d), replaced on a strictly smaller cost only = the two smallest (cost<<16 | d) keys).
  *  S6 WTA right R(p) = argmin_d S(p+d, d) over d with p+d < W, ties -> lowest d,
  *                 integer disparity (not x16), never invalid.
  *  S7 median    3x3 on both maps as u16 (0xFFFF sorts highest); the one-pixel
@@ -159,11 +160,14 @@ void cart_oracle_path_dir(int index, int *dx, int *dy);
 /* S5+S6 on a summed volume S [h][w][D] u16. */
 void cart_oracle_wta(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
                      uint16_t *left, uint16_t *right);
+void cart_oracle_wta_ex(const uint16_t *S, int w, int h, int D, int uniqueness_ratio,
+                        uint16_t *left, uint16_t *right, int variants);   /* variants: CART_ORACLE_VARIANT_S5_TOP2 */
 
-/* The two post-stage choices that are open upstream (NOTEs at S7 / S8 above), selectable so that tests can hold BOTH forms
+/* The three choices that are open upstream (NOTEs at S5 / S7 / S8 above), selectable so that tests can hold BOTH forms
  * against the engine (cart_engine_set_option CART_OPT_SPEC_*) until tools/ref_pin decides; 0 = the spec as written. */
 #define CART_ORACLE_VARIANT_S8_ZERO_INVALID 1      /* LR check also invalidates integer disparity 0 (`d <= 0`) */
 #define CART_ORACLE_VARIANT_S7_REPLICATE_BORDER 2  /* medians read a replicated border instead of passing it through */
+#define CART_ORACLE_VARIANT_S5_TOP2 4              /* uniqueness tests the second-best cost only (the wording of SURVEY.md 8a-4(4)) */
 
 /* S7 */
 void cart_oracle_median3x3_u16(const uint16_t *src, int w, int h, uint16_t *dst);

@@ -89,15 +89,15 @@ def aggregate_path(cl, cr, D, min_disp, p1, p2, dx, dy):
     return L
 
 
-def wta(S, uniqueness_ratio):
+def wta(S, uniqueness_ratio, variants=0):
     h, w, D = S.shape
     S = np.ascontiguousarray(S, np.uint16)
     l = np.empty((h, w), np.uint16); r = np.empty((h, w), np.uint16)
-    lib().cart_oracle_wta(_p(S), w, h, D, uniqueness_ratio, _p(l), _p(r))
+    lib().cart_oracle_wta_ex(_p(S), w, h, D, uniqueness_ratio, _p(l), _p(r), int(variants))
     return l, r
 
 
-VARIANT_S8_ZERO_INVALID, VARIANT_S7_REPLICATE_BORDER = 1, 2   # CART_ORACLE_VARIANT_* (the two choices that are open upstream)
+VARIANT_S8_ZERO_INVALID, VARIANT_S7_REPLICATE_BORDER, VARIANT_S5_TOP2 = 1, 2, 4   # CART_ORACLE_VARIANT_* (the choices that are open upstream)
 
 
 def median3x3(a, variants=0):

@@ -1065,20 +1065,24 @@ def test_pairs_plan_is_refused_where_its_32_bit_sink_offset_would_wrap(torch_cud
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variants", [1, 2, 3])
+@pytest.mark.parametrize("variants", [1, 2, 3, 4, 7])
 def test_spec_variants(torch_cuda, variants):
-    """The two post-SGM choices that are open upstream -- S8: the LR check also invalidates integer disparity 0; S7: medians over
-    a replicated border -- as engine options (CART_OPT_SPEC_*), each and both against the oracle's variants, on images that hit
+    """The three choices that are open upstream -- S8: the LR check also invalidates integer disparity 0; S7: medians over
+    a replicated border; S5: uniqueness from the second-best cost only (the top-2 wording of SURVEY 8a-4(4)) -- as engine
+    options (CART_OPT_SPEC_*), singly and together against the oracle's variants, on images that hit
     them (ragged sizes, a border in every tile shape, min_disparity 0 so that disparity 0 wins often), with interpolation on top;
     and back to the default spec afterwards."""
     torch = torch_cuda
-    for (w, h, D, P, md, scene) in [(173, 67, 64, 8, 0, "road"), (330, 50, 128, 4, 4, "saturated"), (1242, 375, 128, 8, 4, "pole")]:
+    for (w, h, D, P, md, scene) in [(173, 67, 64, 8, 0, "road"), (330, 50, 128, 4, 4, "saturated"), (340, 60, 256, 8, 1, "wall"), (1242, 375, 128, 8, 4, "pole")]:
         l, r, _ = synth.make_pair(w, h, D, md, seed=77, scene=scene)
         base = O.disparity_module(l, r, D, P, md, radius=2, iterations=1)
         exp = O.disparity_module(l, r, D, P, md, radius=2, iterations=1, variants=variants)
         assert (exp != base).any(), "the variant changes nothing on this image: the test would not see a missing switch"
         eng = make_engine(w, h, D, P, md, radius=2, iters=1, inflight=2)
-        eng.set_spec_variants(s8_zero_invalid=bool(variants & 1), s7_replicate_border=bool(variants & 2))
+        eng.set_spec_variants(s8_zero_invalid=bool(variants & 1), s7_replicate_border=bool(variants & 2), s5_top2=bool(variants & 4))
+        if variants & 4:   # the S5 variant lives in the two-kernel WTA: such an engine takes plan SLABS whatever was asked for
+            eng.set_plan("fused_up")
+            assert eng.describe_plan(2)["plan"] == "slabs"
         got = eng.compute_disparity(dev(torch, np.stack([l, l])), dev(torch, np.stack([r, r]))).cpu().numpy()
         assert (got[0] == exp).all() and (got[1] == exp).all(), f"{(w, h, D, P, md, scene)}: {int((got[0] != exp).sum())} pixels differ"
         eng.set_spec_variants()

@@ -29,10 +29,11 @@ def case_inputs(name):
 
 def explain(got, ref, l, r, md, D, P):
     """Which open upstream question (tools/ref_pin/README.md) would account for the difference."""
-    by_variant = {v: int((O.disparity_module(l, r, D, P, md, radius=-1, variants=v) != ref).sum()) for v in (1, 2, 3)}
-    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; with the S8 variant (`d <= 0` invalid) "
-            f"{by_variant[1]} would, with the S7 variant (replicated-border medians) {by_variant[2]}, with both {by_variant[3]} "
-            "(tools/ref_pin/README.md: both are switchable defaults)")
+    by_variant = {v: int((O.disparity_module(l, r, D, P, md, radius=-1, variants=v) != ref).sum()) for v in range(1, 8)}
+    best = min(by_variant, key=by_variant.get)
+    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; by variant set (bit 1 = S8 `d <= 0` invalid, "
+            f"2 = S7 replicated-border medians, 4 = S5 top-2 uniqueness): {by_variant}; the closest is {best} with {by_variant[best]} "
+            "differing pixels (tools/ref_pin/README.md: all three are switchable defaults)")
 
 
 @pytest.mark.skipif(not REF, reason="no reference outputs yet: run tools/ref_pin on a machine with OpenCV-CUDA")
