@@ -1088,3 +1088,25 @@ def test_spec_variants(torch_cuda, variants):
         eng.set_spec_variants()
         assert (eng.compute_disparity(dev(torch, l), dev(torch, r)).cpu().numpy() == base).all()
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,D,P,n", [(173, 67, 64, 4, 16), (201, 45, 128, 8, 8), (330, 50, 256, 8, 16), (131, 90, 256, 4, 24)])
+def test_xcd_placed_launches_cover_every_frame(torch_cuda, w, h, D, P, n):
+    """Launches whose frame count is a multiple of 8 decode their grid per XCD (frames x, x + 8, ... on XCD x; aggregation launch
+    and fused sweep, sgm_kernels.hip xcd_placement): n DISTINCT frames, every launch plan, EVERY frame against the oracle -- a
+    decode that skipped or doubled a (direction, frame, line group) could not hide behind repeated frames."""
+    torch = torch_cuda
+    ls, rs = synth.make_batch(n, w, h, D, 4, seed=5150 + D)
+    exp = [O.disparity_module(ls[k], rs[k], D, P, 4, radius=2, iterations=1) for k in range(n)]
+    assert any((exp[0] != exp[k]).any() for k in range(1, n))
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)
+    eng.set_chunk_frames(n)   # one launch sequence of n frames (24 > the default 16)
+    for plan in ("slabs", "fused_up", "pairs"):
+        eng.set_plan(plan)
+        assert eng.describe_plan(n)["frames_per_launch"] == n
+        got = eng.compute_disparity(dev(torch, ls), dev(torch, rs)).cpu().numpy()
+        for k in range(n):
+            assert (got[k] == exp[k]).all(), f"{plan}, frame {k}: {int((got[k] != exp[k]).sum())} pixels differ"
+    assert eng.device_status() == 0
+    eng.close()
