@@ -211,6 +211,29 @@ typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+// min of three packed u16 pairs in ONE instruction: gfx950's v_pk_minimum3_f16 applied to the bit patterns.  Valid where every operand
+// half is a cost below 0x7C00 (no inf / NaN pattern; non-negative, so IEEE order = unsigned order) -- the recurrence's operands are
+// <= 255 + P2 < 1024, i.e. f16 denormals, which the wave's mode register must preserve (keep_f16_denormals below).  Issue cost as
+// v_pk_min_u16 (profiles/tools/valu_rate.hip), so each use saves one of ~100 instructions of the VALU-bound step.
+#ifndef CART_MIN3
+#define CART_MIN3 1
+#endif
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+#if CART_MIN3
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return pk_min(pk_min(a, b), c);
+#endif
+}
+// MODE.FP_DENORM[3:2] (f16 / f64) = 3: denormals in and out.  It is the code object's default; set explicitly because pk_min3's
+// correctness hangs on it.  hwreg(HW_REG_MODE = 1, offset 6, width 2)
+__device__ __forceinline__ void keep_f16_denormals() {
+#if CART_MIN3
+    __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
+#endif
+}
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
 }
@@ -318,7 +341,7 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         const uint32_t lo = i == 0 ? lo0 : a[i - 1];
         const uint32_t hi = i == 7 ? hi7 : a[i + 1];
         uint32_t t = pk_min(lo, hi) + p1p1;  // no carry between halves (min(lo,hi) is a real cost < 2^15)
-        t = pk_min(pk_min(t, a[i]), mp2);
+        t = pk_min3(t, a[i], mp2);
         // oracle S4: L = C + (min(...) - m).  Every candidate of the min is >= m in both halves, so "- m" is a plain
         // 32-bit subtract; the low-half cost rides on v_bcnt's accumulate operand, the high-half one is shifted in.
         uint32_t u = t - mm;
@@ -347,7 +370,7 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         (void)po;  // the fused WTA consumes the new costs from the registers
     }
     // min over the pixel's D disparities, replicated into both halves
-    uint32_t x = pk_min(pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3])), pk_min(pk_min(n[4], n[5]), pk_min(n[6], n[7])));
+    uint32_t x = pk_min(pk_min3(n[0], n[1], n[2]), pk_min3(n[3], n[4], pk_min3(n[5], n[6], n[7])));
     x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
     mm = group_allmin<LPP>(x);
 #pragma unroll
@@ -482,6 +505,7 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     // own, and every direction re-reads its frame's census planes (4.2 MB per frame).  With n_frames a multiple of 8 the
     // grid is decoded per XCD (xcd_placement() below): XCD x works on frames x, x + 8, ... in the same direction-major order,
     // so that a frame's planes are fetched into ONE L2 instead of all eight.
+    keep_f16_denormals();
     int bid = (int)blockIdx.x, nfr = a.n_frames, frame0 = 0, fstep = 1;
     if (a.xcd_frames) { frame0 = bid & 7; bid >>= 3; nfr = a.n_frames >> 3; fstep = 8; }
     int di = 0;
@@ -819,11 +843,11 @@ __device__ __forceinline__ void pair_step(uint32_t (&a)[8], uint32_t &mm, const 
         const uint32_t lo = i == 0 ? lo0 : a[i - 1];
         const uint32_t hi = i == 7 ? hi7 : a[i + 1];
         uint32_t t = pk_min(lo, hi) + p1p1;
-        t = pk_min(pk_min(t, a[i]), mp2);
+        t = pk_min3(t, a[i], mp2);
         uo[i] = t - mm;            // both halves >= m: plain subtract (see agg_step)
         n[i] = uo[i] + c[i];
     }
-    uint32_t x = pk_min(pk_min(pk_min(n[0], n[1]), pk_min(n[2], n[3])), pk_min(pk_min(n[4], n[5]), pk_min(n[6], n[7])));
+    uint32_t x = pk_min(pk_min3(n[0], n[1], n[2]), pk_min3(n[3], n[4], pk_min3(n[5], n[6], n[7])));
     x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
     mm = group_allmin<LPP>(x);
 #pragma unroll
@@ -839,6 +863,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     __shared__ uint32_t s_shift[2][9][LPP + NT];
     __shared__ uint32_t s_ticket;
     const Geometry &g = a.g;
+    keep_f16_denormals();
     const int tid = threadIdx.x, lane = tid & 63, wid = uniform((int)(threadIdx.x >> 6));
     if (tid == 0) {
         const uint32_t t = atomicAdd(a.ticket, 1u);
@@ -1398,6 +1423,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     constexpr int NTHR = NP <= 4 ? 1024 : 2048;  // sums are <= NP * 255
     __shared__ uint16_t s_thr[NTHR];             // uniqueness threshold by best cost
     const Geometry &g = a.g;
+    keep_f16_denormals();
     const int nblk = (g.w + COLS - 1) / COLS;
     // same XCD placement as aggregate_kernel (frames x, x + 8, ... on XCD x): the sweep re-reads the census planes the
     // aggregation launch has just pulled into that XCD's L2

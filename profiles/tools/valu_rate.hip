@@ -54,6 +54,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
             if (OP == 33) asm volatile("v_min_i32 %0, %0, %1" : "+v"(x) : "v"(b));
             if (OP == 34) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
             if (OP == 35) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+            if (OP == 36) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 37) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 38) asm volatile("v_minimum3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 39) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 40) asm volatile("v_min3_u16 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            if (OP == 41) asm volatile("v_ashr_pk_u8_i32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -80,7 +86,29 @@ void run(const char *name, uint32_t *d, int waves_per_simd) {
            ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
 }
 
+// v_pk_minimum3_f16 on u16 bit patterns below 0x7C00 must equal the unsigned minimum (denormals preserved)
+__global__ void min3_check(uint32_t *bad) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;   // 2^20 threads: a = t & 0x3ff.., walk b, c
+    uint32_t nbad = 0;
+    for (uint32_t k = 0; k < 1024; ++k) {
+        const uint32_t a = (t * 2654435761u >> 7) % 0x7C00u, b = (k * 40503u + t) % 0x7C00u, c = (k * k + 3 * t) % 0x7C00u;
+        const uint32_t pa = a | (b << 16), pb = c | (a << 16), pc = b | (c << 16);
+        uint32_t r;
+        asm volatile("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(pa), "v"(pb), "v"(pc));
+        const uint32_t m = min(a, min(b, c));
+        nbad += r != (m | (m << 16));
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 int main() {
+    {
+        uint32_t *bad, h = 0;
+        hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+        hipLaunchKernelGGL(min3_check, dim3(4096), dim3(256), 0, 0, bad);
+        hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("v_pk_minimum3_f16 vs unsigned min over 2^30 triples of patterns < 0x7C00: %u mismatches\n", h);
+    }
     uint32_t *d;
     hipMalloc(&d, 256 * 8 * 256 * 4);
     for (int w : {4}) {
@@ -94,6 +122,8 @@ int main() {
         run<26>("v_min_f32", d, w); run<27>("v_min_u16", d, w); run<28>("v_max_u32", d, w); run<29>("v_add3_u32", d, w);
         run<30>("v_and_or_b32", d, w); run<31>("v_cndmask_b32", d, w); run<32>("v_pk_add_u16 opsel", d, w); run<33>("v_min_i32", d, w);
         run<34>("v_xad_u32", d, w); run<35>("v_pk_mul_lo_u16", d, w);
+        run<36>("v_pk_minimum3_f16", d, w); run<37>("v_pk_maximum3_f16", d, w); run<38>("v_minimum3_f32", d, w); run<39>("v_bitop3_b32", d, w);
+        run<40>("v_min3_u16", d, w); run<41>("v_ashr_pk_u8_i32", d, w);
     }
     return 0;
 }
