@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--latency", action="store_true", help="also time ONE resident pair, host-synchronous (informational `single_pair_latency`; off by default so that "
+                    "every aggregation / WTA launch of the default command is a full batch and rocprofv3 --stats averages agree with `roofline.launch_ms`)")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (the default)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps steps is run this many times; `value` is the median block, `spread` the fastest / slowest")
@@ -312,7 +314,7 @@ def run(args, world, rank, dev_index):
     # Informational (never `value`): what ONE pair costs when nothing is batched -- the call a SLAM front end makes at camera
     # rate: disparity + plane labelling + CCL of a single resident pair, host-synchronous, median of 30.
     latency = None
-    if rank == 0:
+    if rank == 0 and args.latency:
         lat_pipe = StereoPipeline(eng, provider="static", static_params=(6, 18, -5, 6, 11, 0), with_ccl=True, overlap=False)
         l1, r1 = left[:1], right[:1]
         for _ in range(5):
@@ -495,11 +497,13 @@ def run(args, world, rank, dev_index):
         }
         vi = measured_traffic("aggregate", "valu_insts_per_launch")
         if vi and agg_ms > 0 and not fused:
-            # The aggregation launch is bound by VALU issue, not by HBM: its stored instruction count (SQ_INSTS_VALU of the
-            # committed PMC pass) x 4 cycles per wave64 instruction over 1024 SIMDs, against this run's launch time.  `frac` uses the chip's
-            # 2.4 GHz maximum clock; under this load the chip holds ~1.97 GHz, at which the same figure is `frac_at_held_clock`.
+            # Informational second roofline of the aggregation launch: its stored instruction count (SQ_INSTS_VALU of the committed PMC pass) x 4 cycles
+            # per wave64 instruction over 1024 SIMDs, against this run's launch time.  `frac` uses the chip's 2.4 GHz maximum clock; under this load
+            # the chip holds ~2.0 GHz, at which the same figure is `frac_at_held_clock`.  What binds the launch is the rate at which the memory system
+            # takes its slab writes (profiles/r03_min3.txt: without the stores the launch is 20 % shorter and VALU-bound; with them 11 % fewer
+            # instructions change nothing): the VALU floor sits 15-20 % under the write-bound time.
             issue = vi * 4.0 / 1024.0 / (agg_ms * 1e-3)
-            out["roofline_valu_issue"] = {"bound": "valu-issue (informational)", "kernel": "aggregate_kernel", "valu_insts_per_launch": vi,
+            out["roofline_valu_issue"] = {"bound": "valu-issue (informational: the floor under the write-bound launch)", "kernel": "aggregate_kernel", "valu_insts_per_launch": vi,
                                           "source": "profiles/traffic.json (stored SQ_INSTS_VALU of this configuration)",
                                           "achieved_GHz_equivalent": round(issue / 1e9, 3), "peak_GHz": 2.4, "frac": round(issue / 2.4e9, 4),
                                           "frac_at_held_clock": round(issue / 1.97e9, 4)}

@@ -36,7 +36,7 @@ for k, v in vals.items():
     tj[f"{name}_{w}x{h}_D{D}_P{P}_B{fpl}{suffix}"] = {
         "kernel": k.replace("void cart_amd::", ""), "fetch_size_kb_raw": round(v["FETCH_SIZE"], 1), "write_size_kb": round(v["WRITE_SIZE"], 1),
         "hbm_bytes_per_launch": int(round(v["WRITE_SIZE"] * 1024 + 2 * v["FETCH_SIZE"] * 1024)), "alg_bytes_per_launch": alg, "round": rnd}
-    if "SQ_INSTS_VALU" in v:   # wave-level VALU instructions per launch (the aggregation launch is VALU-issue bound: bench.py prints its issue fraction)
+    if "SQ_INSTS_VALU" in v:   # wave-level VALU instructions per launch (bench.py prints the aggregation launch's issue fraction beside its HBM fraction)
         tj[f"{name}_{w}x{h}_D{D}_P{P}_B{fpl}{suffix}"]["valu_insts_per_launch"] = int(round(v["SQ_INSTS_VALU"]))
 json.dump(tj, open(path, "w"), indent=1)
 print("updated", path, [k for k in tj if k != "_note"])
