@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--latency", action="store_true", help="also time ONE resident pair, host-synchronous (informational `single_pair_latency`; off by default so that "
                     "every aggregation / WTA launch of the default command is a full batch and rocprofv3 --stats averages agree with `roofline.launch_ms`)")
+    ap.add_argument("--placement-tries", type=int, default=4, help="physical placements of the slab workspace the engine may try at set-up (1 = keep the first)")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (the default)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps steps is run this many times; `value` is the median block, `spread` the fastest / slowest")
@@ -244,6 +245,15 @@ def run(args, world, rank, dev_index):
     if args.chunk:
         eng.set_chunk_frames(args.chunk)
     plan = eng.describe_plan(B)   # what the engine will launch: frames per launch sequence, plan, slabs materialised
+    # Untimed set-up, like the allocation itself: the engine times its two slab-bound launches on up to --placement-tries physical
+    # placements of the slab workspace and keeps the fastest (include/cart_engine.h, cart_engine_tune_placement; profiles/r03_alloc.txt)
+    placement = None
+    if args.placement_tries > 1:
+        t_tune = time.perf_counter()
+        ms_first, ms_kept = eng.tune_placement(B, args.placement_tries)
+        placement = {"tries": args.placement_tries, "launch_pair_ms_first": round(ms_first, 4), "launch_pair_ms_kept": round(ms_kept, 4),
+                     "seconds": round(time.perf_counter() - t_tune, 3), "what": "cart_engine_tune_placement: aggregation + WTA launch of one batch on "
+                     "fresh physical placements of the slab workspace, fastest kept (set-up, outside every timed region)"}
     pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=False if args.no_overlap else "auto")
     # this rank's B distinct frames of the sequence (scene translates 2 px per frame), generated once, resident in HBM
     first_frame = rank * B
@@ -521,6 +531,8 @@ def run(args, world, rank, dev_index):
             out["sequence_mode"] = seq
         if latency:
             out["single_pair_latency"] = latency
+        if placement:
+            out["placement_tuning"] = placement
         verified = None
         if not args.no_cpu_baseline:
             # the CPU leg: the oracle timed on the host cores (N = 1 only); the same child also hands back the oracle's outputs of

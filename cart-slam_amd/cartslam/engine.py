@@ -112,6 +112,13 @@ class Engine:
                                                _stream_ptr()), "cart_copy_narrow")
         return dst
 
+    def tune_placement(self, n_frames, max_tries=4):
+        """cart_engine_tune_placement: time the slab-bound launches of an n_frames call on up to max_tries physical placements of the
+        slab workspace and keep the fastest.  -> (ms on the first placement, ms on the kept one).  The engine must be idle."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._lib.cart_engine_tune_placement(self._h, int(n_frames), int(max_tries), C.byref(a), C.byref(b)), "cart_engine_tune_placement")
+        return a.value, b.value
+
     def device_status(self):
         """Synchronises, reads and clears the status word; 0 = healthy (bit 0: a pair sweep of plan "pairs" timed out
         waiting for its neighbour block since the last query -- ask after synchronising when that plan is forced)."""

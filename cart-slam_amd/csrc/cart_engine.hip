@@ -53,6 +53,14 @@ struct TimingRec {
 
 }  // namespace
 
+// The slab workspace: hipMalloc'ed, or (above kSlabChunkBytes) one reserved address range backed by several physical allocations
+struct SlabSet {
+    uint8_t *base = nullptr;
+    size_t reserved = 0;        // bytes of the reserved range (0: `base` comes from hipMalloc)
+    size_t chunk_bytes = 0;     // size of every physical allocation but the last
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+
 struct cart_engine {
     cart_engine_params params;
     Geometry g;
@@ -74,6 +82,8 @@ struct cart_engine {
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
+    SlabSet slab_set;               // what `slabs` points into (slab_alloc / slab_free / cart_engine_tune_placement)
+    size_t slab_bytes_total = 0;
     AggArgs agg_pairs;              // plan PAIRS: right, left, down-left, up-left (the other four ride on the two pair sweeps)
     unsigned long long *pair_xch = nullptr;  // [max_inflight][pair_xch_elems]: block-to-block hand-over of the pair sweeps; first PAIRS call allocates
     uint32_t *pair_ticket = nullptr;         // [max_inflight] block tickets (a lease uses the counter of its first slot)
@@ -242,6 +252,80 @@ int dev_alloc(T **p, size_t count) {
     return 0;
 }
 
+// The slab workspace.  Measured on MI355X (profiles/r03_alloc.txt): the aggregation launch writes its slabs 8-9 % faster into a device
+// allocation of at most 8 GiB than into a larger one (1.41-1.43 against 1.53-1.55 ms per 16 pairs at 1242x375 D=128 P=8; the L2's write
+// requests to the fabric stall 20-30x as often in the larger one; TLB counters and clock are the same) -- whatever the physical layout
+// rule behind it, it goes by the size of the PHYSICAL allocation.  So a workspace above that size is one reserved address range (the
+// kernels keep their "base + frame stride" addressing) backed by separate physical allocations of <= kSlabChunkBytes each.
+constexpr size_t kSlabChunkBytes = ((size_t)8 << 30) - ((size_t)64 << 20);
+
+void slab_free(SlabSet &ss) {
+    if (!ss.base) return;
+    if (ss.reserved) {
+        size_t off = 0;
+        for (auto &h : ss.chunks) {   // one unmap per mapping, with the mapping's own size
+            const size_t sz = std::min(ss.chunk_bytes, ss.reserved - off);
+            (void)hipMemUnmap(ss.base + off, sz);
+            (void)hipMemRelease(h);
+            off += sz;
+        }
+        (void)hipMemAddressFree(ss.base, ss.reserved);
+    } else {
+        (void)hipFree(ss.base);
+    }
+    ss = SlabSet{};
+}
+
+int slab_alloc(SlabSet &ss, int device_id, size_t bytes, size_t chunk_bytes) {
+    ss = SlabSet{};
+    if (bytes <= chunk_bytes) return dev_alloc(&ss.base, bytes);
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device_id;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+        (void)hipGetLastError();
+        return dev_alloc(&ss.base, bytes);   // no virtual memory management on this device: one allocation
+    }
+    const size_t chunk = std::max(gran, chunk_bytes / gran * gran), total = (bytes + gran - 1) / gran * gran;
+    void *base = nullptr;
+    if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return dev_alloc(&ss.base, bytes);
+    }
+    ss.base = static_cast<uint8_t *>(base);
+    ss.reserved = total;
+    ss.chunk_bytes = chunk;
+    size_t mapped = 0;
+    hipError_t err = hipSuccess;
+    for (size_t off = 0; off < total && err == hipSuccess; off += chunk) {
+        const size_t sz = std::min(chunk, total - off);
+        hipMemGenericAllocationHandle_t h;
+        err = hipMemCreate(&h, sz, &prop, 0);
+        if (err != hipSuccess) break;
+        ss.chunks.push_back(h);
+        err = hipMemMap(ss.base + off, sz, 0, h, 0);
+        if (err != hipSuccess) break;
+        mapped = off + sz;
+    }
+    if (err == hipSuccess) {   // ONE call over the whole range: on ROCm 7.2 a hipMemSetAccess per mapping leaves the range inaccessible
+        hipMemAccessDesc acc{};   // (memory access fault on first touch; profiles/tools/vmm_test.hip)
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        err = hipMemSetAccess(ss.base, total, &acc, 1);
+    }
+    if (err != hipSuccess) {
+        for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(ss.base + off, std::min(chunk, total - off));
+        for (auto &h : ss.chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(ss.base, total);
+        ss = SlabSet{};
+        (void)hipGetLastError();
+        return dev_alloc(&ss.base, bytes);   // whatever failed: one plain allocation still gives a working (slower) workspace
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,6 +343,10 @@ void cart_engine_default_params(cart_engine_params *p) {
     p->smoothing_iterations = 5;  // cartconfig.cpp:151
     p->max_inflight = 12;       // CARTSLAM_CONCURRENT_RUN_LIMIT, cartslam.hpp:4
 }
+
+#ifdef CART_EXPERIMENTS
+extern "C" const void *cart_debug_slab_base(const cart_engine *e) { return e ? e->slabs : nullptr; }
+#endif
 
 int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     if (!out) return fail("out is NULL");
@@ -305,7 +393,15 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     e->cen_slack = (size_t)4 * g.cpitch + g.h + 1024;
     rc |= dev_alloc(&e->cen_l_alloc, n * g.census_elems + 2 * e->cen_slack);
     rc |= dev_alloc(&e->cen_r_alloc, n * g.census_elems + 2 * e->cen_slack);
-    rc |= dev_alloc(&e->slabs, n * g.P * g.slab_bytes);
+    e->slab_bytes_total = n * g.P * g.slab_bytes;
+#ifdef CART_EXPERIMENTS   // address-mapping experiments: CART_SLAB_CHUNK_MIB = 0: one hipMalloc whatever the size; else that chunk size
+    if (const char *ck = std::getenv("CART_SLAB_CHUNK_MIB")) {
+        const size_t mib = std::strtoull(ck, nullptr, 0);
+        rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total, mib ? mib << 20 : ~(size_t)0);
+    } else
+#endif
+    rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total, kSlabChunkBytes);
+    e->slabs = e->slab_set.base;
     rc |= dev_alloc(&e->wta_l, n * g.npx);
     rc |= dev_alloc(&e->right_pk, n * g.npx);
     rc |= dev_alloc(&e->tmp_a, n * g.npx);
@@ -350,7 +446,8 @@ void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->slabs, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
+    slab_free(e->slab_set);
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
                     e->pair_xch, e->pair_ticket, e->dev_status, e->uniq_thr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -423,6 +520,94 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
     out->plan = plan_for(e, o, out->frames_per_launch);
     out->slabs_written = out->plan == CART_PLAN_PAIRS ? 6 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
     return 0;
+}
+
+namespace {
+// Time of the aggregation + WTA launches of `n` frames at slots [s0, s0 + n) with the slab workspace at `slabs` (ms, best of two after one
+// warm-up; the census planes hold whatever they hold: the cost of these launches does not depend on the data).  < 0 on error.
+float probe_placement(cart_engine *e, const Options &opt, uint8_t *slabs_base, size_t s0, int n, hipEvent_t ev0, hipEvent_t ev1) {
+    const Geometry &g = e->g;
+    uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
+    uint8_t *slabs = slabs_base + s0 * g.P * g.slab_bytes;
+    uint16_t *wl = e->wta_l + s0 * g.npx;
+    uint32_t *rpk = e->right_pk + s0 * g.npx;
+    const bool fused = plan_for(e, opt, n) == CART_PLAN_FUSED_UP && e->rv_partial;
+    float best = -1.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        if (hipMemsetAsync(rpk, 0xff, (size_t)n * g.npx * sizeof(uint32_t), nullptr) != hipSuccess) return -1.f;   // what launch_census leaves there
+        if (hipEventRecord(ev0, nullptr) != hipSuccess) return -1.f;
+        AggArgs a = fused ? e->agg_fused : e->agg;
+        a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
+        launch_aggregate(a, n, nullptr);
+        if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, nullptr);
+        else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, nullptr, false);
+        if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.f;
+        if (rep && (best < 0.f || ms < best)) best = ms;
+    }
+    return best;
+}
+}  // namespace
+
+int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, float *ms_first, float *ms_kept) {
+    if (!e) return fail("engine is NULL");
+    if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
+    if (n_frames < 1 || n_frames > (int)e->slots.size()) return fail("n_frames must be in [1, max_inflight]");
+    if (ms_first) *ms_first = 0.f;
+    if (ms_kept) *ms_kept = 0.f;
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    std::unique_lock<std::mutex> lk(e->mu);
+    for (const auto &sl : e->slots)
+        if (sl.busy) return fail("cart_engine_tune_placement needs an idle engine");
+    const Options opt = snapshot_options(e);
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = std::min(n_frames, opt.chunk_frames);
+    if (plan_for(e, opt, n) == CART_PLAN_FUSED_UP && !e->rv_partial)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(e->g) * sizeof(uint32_t)));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    HIP_TRY(hipEventCreate(&ev0));
+    if (hipEventCreate(&ev1) != hipSuccess) { (void)hipEventDestroy(ev0); return fail("hipEventCreate failed"); }
+    // every full group of n slots is probed (at most four groups): a caller with several calls in flight uses them all
+    const int groups = std::max(1, std::min(4, (int)e->slots.size() / n));
+    auto score = [&](uint8_t *base) {
+        float sum = 0.f;
+        for (int gi = 0; gi < groups; ++gi) {
+            const float t = probe_placement(e, opt, base, (size_t)gi * n, n, ev0, ev1);
+            if (t < 0.f) return -1.f;
+            sum += t;
+        }
+        return sum / groups;
+    };
+    float kept = score(e->slab_set.base);
+    if (ms_first) *ms_first = kept;
+    std::vector<SlabSet> losers;   // kept allocated until the end: a freed placement would be handed out again
+    int rc = 0;
+    for (int t = 1; t < max_tries && kept >= 0.f; ++t) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->slab_bytes_total + ((size_t)4 << 30)) break;   // no room for another candidate
+        SlabSet cand;
+        if (slab_alloc(cand, e->params.device_id, e->slab_bytes_total, kSlabChunkBytes)) { (void)hipGetLastError(); break; }
+        const float sc = score(cand.base);
+#ifdef CART_EXPERIMENTS
+        std::fprintf(stderr, "tune_placement: try %d  %.4f ms (kept so far %.4f)\n", t, sc, kept);
+#endif
+        if (sc < 0.f) { slab_free(cand); rc = fail("placement probe failed"); break; }
+        if (sc < kept) {
+            losers.push_back(std::move(e->slab_set));
+            e->slab_set = std::move(cand);
+            e->slabs = e->slab_set.base;
+            kept = sc;
+        } else {
+            losers.push_back(std::move(cand));
+        }
+    }
+    (void)hipDeviceSynchronize();
+    for (auto &l : losers) slab_free(l);
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    if (kept < 0.f && rc == 0) rc = fail("placement probe failed");
+    if (ms_kept) *ms_kept = kept;
+    return rc;
 }
 
 int cart_engine_device_status(cart_engine *e, unsigned *status) {

@@ -68,6 +68,12 @@ struct ScopedStream {
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 
+// CARTSLAM_PLACEMENT_TRIES = placements of the slab workspace cart_engine_tune_placement may try (default 4; 1 = keep the first)
+int placementTries() {
+    const char *env = std::getenv("CARTSLAM_PLACEMENT_TRIES");
+    return env ? std::max(1, std::atoi(env)) : 4;
+}
+
 cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int radius, int iterations, int paths, int p1, int p2, int uniq) {
     cart_engine_params p;
     cart_engine_default_params(&p);
@@ -81,6 +87,10 @@ cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int
 
 EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
     if (cart_engine_create(&params, &engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
+    // Pick the fastest of a few physical placements of the cost-slab workspace (include/cart_engine.h, cart_engine_tune_placement: the
+    // aggregation launch runs 8-9 % faster on some; ~65 ms once per module).  Not fatal: a failed probe leaves the first placement.
+    if (params.num_disparities > 0 && placementTries() > 1)
+        (void)cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), nullptr, nullptr);
 }
 EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }
 void EngineHandle::fail(const char *what) const { throw std::runtime_error(std::string(what) + ": " + cart_last_error(engine)); }

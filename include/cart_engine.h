@@ -112,6 +112,18 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * module adapters never force a plan and need not ask. */
 int cart_engine_device_status(cart_engine *engine, unsigned *status);
 
+/* Placement tuning of the cost-slab workspace (no reference counterpart; optional).  On MI355X the time of the two slab-bound launches
+ * depends on WHICH physical memory backs the slabs: the same kernels on the same addresses run in one of two modes per allocation
+ * (aggregation 1.41-1.43 or 1.53-1.55 ms, WTA 1.15 or 1.27 ms per 16 pairs at 1242x375 D=128 P=8; profiles/r03_alloc.txt: the L2's write
+ * requests to the fabric stall 20-30x as often in the slow mode, TLB misses and clock are the same; allocations above 8 GiB are always
+ * slow, which is why the engine backs a larger workspace with several physical allocations behind one address range).  This call times
+ * the aggregation + WTA launches of `n_frames` frames on the current workspace, then on up to `max_tries - 1` freshly allocated ones
+ * (each needs the workspace's size in free device memory for the moment), keeps the fastest and frees the others.  The engine must
+ * be idle; results do not change (every placement gives the same bits).  ms_first / ms_kept (may be NULL): mean launch-pair time over
+ * the probed slot groups before and after.  Call it once after cart_engine_create / cart_engine_set_option when creation time does
+ * not matter (about 20-60 ms per try). */
+int cart_engine_tune_placement(cart_engine *engine, int n_frames, int max_tries, float *ms_first, float *ms_kept);
+
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
  * create when engine == NULL).  Never NULL. */
 const char *cart_last_error(const cart_engine *engine);

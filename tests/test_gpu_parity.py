@@ -1110,3 +1110,38 @@ def test_xcd_placed_launches_cover_every_frame(torch_cuda, w, h, D, P, n):
             assert (got[k] == exp[k]).all(), f"{plan}, frame {k}: {int((got[k] != exp[k]).sum())} pixels differ"
     assert eng.device_status() == 0
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,P,inflight", [(128, 8, 40), (256, 4, 6), (64, 4, 8)])
+def test_placement_tuning_keeps_the_bits(torch_cuda, D, P, inflight):
+    """cart_engine_tune_placement (the slab workspace re-allocated a few times, the fastest placement kept; above 8 GiB the workspace
+    is one address range over several physical allocations) changes no result: every slot group gives the oracle's disparity before and
+    after, with every plan; the reported times are positive and the kept one is not slower than the first."""
+    torch = torch_cuda
+    w, h, B = 1242, 375, 3
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=inflight)   # D=128 P=8 x 40 slots = 19 GB: three physical chunks
+    ls, rs = synth.make_batch(B, w, h, D, 4, scene="stripes")
+    l, r = dev(torch, ls), dev(torch, rs)
+    want = O.disparity_module(ls[1], rs[1], D, P, 4, radius=2, iterations=1)
+    def all_groups():
+        # leases are handed out lowest-first on one stream: hold earlier outputs so that later calls move up the slots
+        outs = []
+        for plan in ("slabs", "fused_up", "auto"):
+            eng.set_plan(plan)
+            outs.append(eng.compute_disparity(l, r))
+        return outs
+    before = [o.cpu().numpy() for o in all_groups()]
+    first, kept = eng.tune_placement(B, 3)
+    assert first > 0 and 0 < kept <= first
+    after = [o.cpu().numpy() for o in all_groups()]
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a[1], want)
+    # one call over every slot: launch sequences in every physical chunk, one of them across a chunk boundary
+    lsb, rsb = synth.make_batch(inflight, w, h, D, 4)
+    eng.set_plan("auto")
+    d1 = eng.compute_disparity(dev(torch, lsb), dev(torch, rsb)).cpu().numpy()
+    for f in sorted({0, inflight // 2, 17 % inflight, inflight - 1}):
+        assert np.array_equal(d1[f], O.disparity_module(lsb[f], rsb[f], D, P, 4, radius=2, iterations=1)), f
+    eng.close()
