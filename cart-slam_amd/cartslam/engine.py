@@ -112,7 +112,7 @@ class Engine:
                                                _stream_ptr()), "cart_copy_narrow")
         return dst
 
-    def tune_placement(self, n_frames, max_tries=4):
+    def tune_placement(self, n_frames, max_tries=10):
         """cart_engine_tune_placement: time the slab-bound launches of an n_frames call on up to max_tries physical placements of the
         slab workspace and keep the fastest.  -> (ms on the first placement, ms on the kept one).  The engine must be idle."""
         a, b = C.c_float(0), C.c_float(0)

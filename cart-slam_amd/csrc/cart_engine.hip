@@ -1,6 +1,7 @@
 // cart_engine.hip -- C-ABI implementation (include/cart_engine.h): workspace pool, stage
 // sequencing and the host-side peak finder.  No exceptions cross the ABI and nothing exits.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -539,11 +540,23 @@ float probe_placement(cart_engine *e, const Options &opt, uint8_t *slabs_base, s
         AggArgs a = fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, nullptr);
+#ifdef CART_EXPERIMENTS   // the two launches timed apart (stderr), for the placement study
+        hipEvent_t evm = nullptr;
+        if (rep == 2 && hipEventCreate(&evm) == hipSuccess) (void)hipEventRecord(evm, nullptr);
+#endif
         if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, nullptr);
         else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, nullptr, false);
         if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.f;
+#ifdef CART_EXPERIMENTS
+        if (evm) {
+            float ma = 0.f;
+            (void)hipEventElapsedTime(&ma, ev0, evm);
+            std::fprintf(stderr, "probe slots %zu..: aggregate %.4f wta %.4f\n", s0, ma, ms - ma);
+            (void)hipEventDestroy(evm);
+        }
+#endif
         if (rep && (best < 0.f || ms < best)) best = ms;
     }
     return best;
@@ -568,22 +581,31 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, floa
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     HIP_TRY(hipEventCreate(&ev0));
     if (hipEventCreate(&ev1) != hipSuccess) { (void)hipEventDestroy(ev0); return fail("hipEventCreate failed"); }
-    // every full group of n slots is probed (at most four groups): a caller with several calls in flight uses them all
+    // Every full group of n slots is probed (at most four groups): a caller with several calls in flight uses them all.  Leases are
+    // first-fit (acquire), so the lowest group carries most calls -- all of them for a caller with one call in flight: it counts three times.
     const int groups = std::max(1, std::min(4, (int)e->slots.size() / n));
     auto score = [&](uint8_t *base) {
         float sum = 0.f;
         for (int gi = 0; gi < groups; ++gi) {
             const float t = probe_placement(e, opt, base, (size_t)gi * n, n, ev0, ev1);
             if (t < 0.f) return -1.f;
-            sum += t;
+            sum += gi == 0 ? 3.f * t : t;
         }
-        return sum / groups;
+        return sum / (groups + 2);
     };
+    const auto t_begin = std::chrono::steady_clock::now();
     float kept = score(e->slab_set.base);
     if (ms_first) *ms_first = kept;
-    std::vector<SlabSet> losers;   // kept allocated until the end: a freed placement would be handed out again
+    float worst = kept;
+    std::vector<SlabSet> losers;   // all stay allocated until the end (the free-memory check below bounds them): a placement freed at once
+                                   // would be handed out again, and address ranges recycled while others are live have faulted on ROCm 7.2
     int rc = 0;
     for (int t = 1; t < max_tries && kept >= 0.f; ++t) {
+        // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
+        // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
+        // Allocating tens of GB takes ~0.1 s per candidate: no more than ~1.5 s in all.
+        if (kept < 0.885f * worst) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5) break;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->slab_bytes_total + ((size_t)4 << 30)) break;   // no room for another candidate
         SlabSet cand;
@@ -593,6 +615,7 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, floa
         std::fprintf(stderr, "tune_placement: try %d  %.4f ms (kept so far %.4f)\n", t, sc, kept);
 #endif
         if (sc < 0.f) { slab_free(cand); rc = fail("placement probe failed"); break; }
+        worst = std::max(worst, sc);
         if (sc < kept) {
             losers.push_back(std::move(e->slab_set));
             e->slab_set = std::move(cand);

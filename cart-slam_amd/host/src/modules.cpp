@@ -68,10 +68,10 @@ struct ScopedStream {
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 
-// CARTSLAM_PLACEMENT_TRIES = placements of the slab workspace cart_engine_tune_placement may try (default 4; 1 = keep the first)
+// CARTSLAM_PLACEMENT_TRIES = placements of the slab workspace cart_engine_tune_placement may try (default 10, it stops at the first fast one; 1 = keep the first)
 int placementTries() {
     const char *env = std::getenv("CARTSLAM_PLACEMENT_TRIES");
-    return env ? std::max(1, std::atoi(env)) : 4;
+    return env ? std::max(1, std::atoi(env)) : 10;
 }
 
 cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int radius, int iterations, int paths, int p1, int p2, int uniq) {

@@ -102,7 +102,7 @@ FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params p
         params.device_id = devices[r];
         params.max_inflight = framesPerGpu;
         if (cart_engine_create(&params, &rank->engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
-        (void)cart_engine_tune_placement(rank->engine, std::min(framesPerGpu, 16), 4, nullptr, nullptr);   // fastest of four slab placements (cart_engine.h)
+        (void)cart_engine_tune_placement(rank->engine, std::min(framesPerGpu, 16), 10, nullptr, nullptr);   // a fast slab placement among up to ten (cart_engine.h)
         cartOk(cart_plane_schedule_create(rank->engine, /*histogram_peak*/ 1, nullptr, updateInterval, resetInterval, &rank->schedule), rank->engine,
                "cart_plane_schedule_create");
         for (int b = 0; b < 2; ++b) {
