@@ -218,9 +218,6 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 #ifndef CART_MIN3
 #define CART_MIN3 1
 #endif
-#ifndef CART_WTA_XCD
-#define CART_WTA_XCD 0
-#endif
 __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
 #if CART_MIN3
     uint32_t r;
@@ -1149,17 +1146,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     uint16_t *wta_l = a.wta_l;
     uint32_t *right_pk = a.right_pk;
     const Geometry &g = a.g;
-#if CART_WTA_XCD   // experiment: a frame's tiles on ONE XCD (frames x, x + 8, ... on XCD x), like the aggregation launch
-    int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tpf = gridDim.x * gridDim.y, r = lin >> 3;
-        frame = (int)((lin & 7u) + 8u * (r / tpf));
-        const unsigned t = r % tpf;
-        x0 = (int)(t % gridDim.x) * kWtaTileX; y = (int)(t / gridDim.x);
-    }
-#else
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
-#endif
     const int grp = threadIdx.x / LPP, gl = threadIdx.x % LPP, d0 = gl * 16;
     // Right view: every lane min-reduces its 16 (S << 16 | d) keys into the tile's array indexed by p = x - d (ds_min_u32),
     // slot p - (x0 - (D-1)).  (Walking the tile's diagonals per right pixel instead -- 64 dependent LDS reads on 127 of

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs a "wtaxcd" experiment build of a tree that still has the CART_WTA_XCD hook: kept as the record of the command)
 # usage (GPU box): r03_wtaxcd.sh <tag> -- parity of the variant, then per-placement probe times (aggregate, wta) of the experiment builds
 # "addr" (product kernels) and "wtaxcd" (WTA tiles of a frame on one XCD), 10 placements x 2 slot groups per process, 3 processes each
 R=$GRAFT_REPO_ROOT; T=$1; O=$R/gpurun_out/$T; mkdir -p $O
