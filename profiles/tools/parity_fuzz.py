@@ -30,12 +30,23 @@ while time.time() - t0 < budget:
     chunk = rng.choice((0, 0, 0, 1, 2, 3))
     ch = rng.choice((1, 1, 3)); scene = rng.choice(synth.SCENES); s = rng.randint(0, 1 << 30)
     desc = f"w={w} h={h} D={D} P={P} md={md} p1={p1} p2={p2} uniq={uniq} r={radius} it={iters} var={variants} plan={plan} B={B} chunk={chunk} ch={ch} scene={scene} seed={s}"
+    # a third of the cases tune the slab placement first (cart_engine_tune_placement: the workspace is swapped for another one); some give the
+    # engine more slots than the call needs, large cases up to a workspace above 8 GiB (several physical allocations behind one address range)
+    inflight = B
+    if rng.random() < 0.3:
+        inflight = B + rng.randint(1, 24)
+        while inflight > B and inflight * w * h * D * P > 24e9:
+            inflight -= 1
+    tune = rng.random() < 0.33
+    desc += f" inflight={inflight} tune={int(tune)}"
     eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=md, p1=p1, p2=p2, uniqueness_ratio=uniq, smoothing_radius=radius,
-                 smoothing_iterations=iters, max_inflight=B)
+                 smoothing_iterations=iters, max_inflight=inflight)
     eng.set_plan(plan)
     if chunk:
         eng.set_chunk_frames(chunk)
     eng.set_spec_variants(s8_zero_invalid=bool(variants & 1), s7_replicate_border=bool(variants & 2), s5_top2=bool(variants & 4))
+    if tune:
+        eng.tune_placement(B, 3)
     pairs = [synth.make_pair(w, h, D, md, seed=s + k, frame=k, channels=ch, scene=scene)[:2] for k in range(B)]
     L = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda(); R = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
     got = eng.compute_disparity(L, R).cpu().numpy()
