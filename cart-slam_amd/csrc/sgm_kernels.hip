@@ -765,7 +765,10 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     // and the census planes the directions re-read stay in L2.  Smaller workgroups are slower (two waves or one: the headline's
     // launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64.
     constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
-    const int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
+    int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
+#ifdef CART_EXPERIMENTS
+    if (const char *e = std::getenv("CART_AGG_RESIDENT")) resident = std::atoi(e);
+#endif
     const int lpp = a.g.D / 16;
     const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
     // (never more than 64 KB per workgroup in all, the limit that needs no opt-in: two of those per CU are still two)
