@@ -88,7 +88,7 @@ cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int
 EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
     if (cart_engine_create(&params, &engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
     // Pick the fastest of a few physical placements of the cost-slab workspace (include/cart_engine.h, cart_engine_tune_placement: the
-    // aggregation launch runs 8-9 % faster on some; ~65 ms once per module).  Not fatal: a failed probe leaves the first placement.
+    // aggregation launch runs 8-9 % faster on some; 0.03-0.2 s once per module, seconds when the allocator is slow).  Not fatal: a failed probe leaves the first placement.
     if (params.num_disparities > 0 && placementTries() > 1)
         (void)cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), nullptr, nullptr);
 }
