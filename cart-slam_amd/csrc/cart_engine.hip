@@ -603,9 +603,9 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, floa
     for (int t = 1; t < max_tries && kept >= 0.f; ++t) {
         // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
         // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
-        // Allocating tens of GB takes ~0.1 s per candidate: no more than ~1.5 s in all.
+        // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 1.5 s + 1 s per 20 GB of workspace in all.
         if (kept < 0.885f * worst) break;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5 + (double)e->slab_bytes_total / 20e9) break;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->slab_bytes_total + ((size_t)4 << 30)) break;   // no room for another candidate
         SlabSet cand;
