@@ -497,8 +497,9 @@ def run(args, world, rank, dev_index):
                          # bytes the launch plan really has to move (equal to the table's for plan slabs); the copy-ceiling
                          # fraction is priced with these, so a plan that skips slabs cannot print more than 1
                          "moved_bytes_per_launch": moved_bytes, "frac_moved": round(moved_gbps / HBM_PEAK_GBS, 4),
-                         # device-to-device copy of 2 GiB on this box, bytes read + written per second: half of it is reads, so a
-                         # write-mostly launch (the aggregation writes 7x what it reads) can come out slightly above 1
+                         # device-to-device copy of 2 GiB on this box, bytes read + written per second: a reference rate, not a bound --
+                         # half of a copy is reads; the aggregation launch is nine tenths writes and on a good placement of its slabs
+                         # (placement_tuning) moves its bytes 4-15 % faster than the copy does (write-only stream: 5.7 TB/s)
                          "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_copy_ceiling": round(moved_gbps / copy_gbps, 4) if copy_gbps else None},
             "stages_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},

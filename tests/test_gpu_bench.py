@@ -26,7 +26,7 @@ def test_single_gpu_line_is_verified_and_complete():
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
     d = one_json_line(pr.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline", "spread", "repeats", "prewarm_steps", "verified"):
+              "config", "roofline", "cpu_baseline", "spread", "repeats", "prewarm_steps", "verified", "placement_tuning"):
         assert k in d, k
     assert d["verified"] is True and d["verification"]["mismatches"] == []
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["repeats"] == 3 and d["value"] > 0
@@ -34,9 +34,11 @@ def test_single_gpu_line_is_verified_and_complete():
     assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3      # value = pairs of the median block / its time
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["frac_of_copy_ceiling"] is None or r["frac_of_copy_ceiling"] <= 1.0
+    assert r["frac_of_copy_ceiling"] is None or 0 < r["frac_of_copy_ceiling"] <= 1.3   # a reference rate (half reads), not a bound: DESIGN.md 5
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["config"]["distinct_frames_per_batch"] == 4
+    pt = d["placement_tuning"]
+    assert 0 < pt["launch_pair_ms_kept"] <= pt["launch_pair_ms_first"] and pt["tries"] >= 1
 
 
 def test_two_ranks_through_the_drivers_launch_form():
