@@ -83,6 +83,7 @@ struct cart_engine {
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
+    size_t slab_slack = 0;          // experiment builds only
     SlabSet slab_set;               // what `slabs` points into (slab_alloc / slab_free / cart_engine_tune_placement)
     size_t slab_bytes_total = 0;
     AggArgs agg_pairs;              // plan PAIRS: right, left, down-left, up-left (the other four ride on the two pair sweeps)
@@ -347,6 +348,14 @@ void cart_engine_default_params(cart_engine_params *p) {
 
 #ifdef CART_EXPERIMENTS
 extern "C" const void *cart_debug_slab_base(const cart_engine *e) { return e ? e->slabs : nullptr; }
+// placement study: with CART_SLAB_SLACK_MIB set at create the slab allocation has that much room behind it, and the slabs can be moved inside
+// it (idle engine): same physical allocation, another offset
+extern "C" int cart_debug_set_slab_shift(cart_engine *e, size_t bytes) {
+    if (!e || (bytes & 255) || bytes > e->slab_slack) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    e->slabs = e->slab_set.base + bytes;
+    return 0;
+}
 #endif
 
 int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
@@ -396,7 +405,10 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     rc |= dev_alloc(&e->cen_r_alloc, n * g.census_elems + 2 * e->cen_slack);
     e->slab_bytes_total = n * g.P * g.slab_bytes;
 #ifdef CART_EXPERIMENTS   // address-mapping experiments: CART_SLAB_CHUNK_MIB = 0: one hipMalloc whatever the size; else that chunk size
-    if (const char *ck = std::getenv("CART_SLAB_CHUNK_MIB")) {
+    if (const char *sk = std::getenv("CART_SLAB_SLACK_MIB")) {
+        e->slab_slack = (size_t)std::strtoull(sk, nullptr, 0) << 20;
+        rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total + e->slab_slack, kSlabChunkBytes);
+    } else if (const char *ck = std::getenv("CART_SLAB_CHUNK_MIB")) {
         const size_t mib = std::strtoull(ck, nullptr, 0);
         rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total, mib ? mib << 20 : ~(size_t)0);
     } else
