@@ -250,7 +250,7 @@ def run(args, world, rank, dev_index):
     placement = None
     if args.placement_tries > 1:
         t_tune = time.perf_counter()
-        ms_first, ms_kept = eng.tune_placement(B, args.placement_tries)
+        ms_first, ms_kept = eng.tune_placement(B, args.placement_tries, max_extra_bytes=None)   # set-up of a dedicated bench process: no byte cap (4 GiB stay free)
         placement = {"tries": args.placement_tries, "launch_pair_ms_first": round(ms_first, 4), "launch_pair_ms_kept": round(ms_kept, 4),
                      "seconds": round(time.perf_counter() - t_tune, 3), "what": "cart_engine_tune_placement: aggregation + WTA launch of one batch on "
                      "fresh physical placements of the slab workspace, fastest kept (set-up, outside every timed region)"}

@@ -55,7 +55,7 @@ PROTOTYPES = {
     "cart_engine_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "cart_engine_describe_plan": (_i, [_vp, _i, C.POINTER(LaunchPlan)]),
     "cart_engine_device_status": (_i, [_vp, C.POINTER(C.c_uint)]),
-    "cart_engine_tune_placement": (_i, [_vp, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cart_engine_tune_placement": (_i, [_vp, _i, _i, _sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cart_compute_disparity": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
     "cart_compute_disparity_batch": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp]),
     "cart_compute_disparity_multi": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),

@@ -112,11 +112,14 @@ class Engine:
                                                _stream_ptr()), "cart_copy_narrow")
         return dst
 
-    def tune_placement(self, n_frames, max_tries=10):
-        """cart_engine_tune_placement: time the slab-bound launches of an n_frames call on up to max_tries physical placements of the
-        slab workspace and keep the fastest.  -> (ms on the first placement, ms on the kept one).  The engine must be idle."""
+    def tune_placement(self, n_frames, max_tries=10, max_extra_bytes=0):
+        """cart_engine_tune_placement (opt-in set-up step): time the slab-bound launches of an n_frames call on up to max_tries physical
+        placements of the slot groups behind it and keep the fastest.  max_extra_bytes bounds what the call may hold beyond the
+        workspace while it searches (0: two units' worth; None: no cap but 4 GiB left free).  -> (ms before, ms after).  The engine
+        must be idle."""
         a, b = C.c_float(0), C.c_float(0)
-        self._check(self._lib.cart_engine_tune_placement(self._h, int(n_frames), int(max_tries), C.byref(a), C.byref(b)), "cart_engine_tune_placement")
+        cap = C.c_size_t(-1).value if max_extra_bytes is None else int(max_extra_bytes)
+        self._check(self._lib.cart_engine_tune_placement(self._h, int(n_frames), int(max_tries), cap, C.byref(a), C.byref(b)), "cart_engine_tune_placement")
         return a.value, b.value
 
     def device_status(self):

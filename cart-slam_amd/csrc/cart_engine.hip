@@ -54,12 +54,18 @@ struct TimingRec {
 
 }  // namespace
 
-// The slab workspace: hipMalloc'ed, or (above kSlabChunkBytes) one reserved address range backed by several physical allocations
-struct SlabSet {
-    uint8_t *base = nullptr;
-    size_t reserved = 0;        // bytes of the reserved range (0: `base` comes from hipMalloc)
-    size_t chunk_bytes = 0;     // size of every physical allocation but the last
-    std::vector<hipMemGenericAllocationHandle_t> chunks;
+// The slab workspace: one plain hipMalloc per GROUP of workspace slots, no group larger than kSlabChunkBytes (see slab_pool_alloc).
+// Slot s lives at base[s / group_slots] + (s % group_slots) * slot_bytes; the kernels of a launch get the slab pointers of their
+// frames as a table (SlabTable), so a launch may span groups.
+struct SlabPool {
+    std::vector<uint8_t *> base;   // one device allocation per group
+    int group_slots = 0;           // slots per group (the last group may hold fewer)
+    int slots = 0;
+    size_t slot_bytes = 0;         // P path slabs of one frame
+    int groups() const { return (int)base.size(); }
+    int slots_of(int gi) const { return std::min(group_slots, slots - gi * group_slots); }
+    size_t bytes_of(int gi) const { return (size_t)slots_of(gi) * slot_bytes; }
+    uint8_t *slot_ptr(int s) const { return base[s / group_slots] + (size_t)(s % group_slots) * slot_bytes; }
 };
 
 struct cart_engine {
@@ -72,7 +78,6 @@ struct cart_engine {
     uint32_t *cen_l = nullptr, *cen_r = nullptr;      // point `cen_slack` elements into their allocations
     uint32_t *cen_l_alloc = nullptr, *cen_r_alloc = nullptr;
     size_t cen_slack = 0;
-    uint8_t *slabs = nullptr;
     uint16_t *wta_l = nullptr;
     uint32_t *right_pk = nullptr;
     int16_t *tmp_a = nullptr, *tmp_b = nullptr;  // tight s16 planes (interpolate ping-pong)
@@ -83,9 +88,7 @@ struct cart_engine {
     unsigned *sp_votes = nullptr;   // [max_inflight][kSpMaxLabels*3], allocated by the first cart_superpixel_plane_classify
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
-    size_t slab_slack = 0;          // experiment builds only
-    SlabSet slab_set;               // what `slabs` points into (slab_alloc / slab_free / cart_engine_tune_placement)
-    size_t slab_bytes_total = 0;
+    SlabPool slab_pool;             // the cost slabs of every slot (slab_pool_alloc / slab_pool_free / cart_engine_tune_placement)
     AggArgs agg_pairs;              // plan PAIRS: right, left, down-left, up-left (the other four ride on the two pair sweeps)
     unsigned long long *pair_xch = nullptr;  // [max_inflight][pair_xch_elems]: block-to-block hand-over of the pair sweeps; first PAIRS call allocates
     uint32_t *pair_ticket = nullptr;         // [max_inflight] block tickets (a lease uses the counter of its first slot)
@@ -210,7 +213,7 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     }
     a.ndirs = nd;
     a.blocks_per_frame = blk;
-    a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = e->slabs;
+    a.cen_l = e->cen_l; a.cen_r = e->cen_r; a.slabs = SlabTable{};   // filled per launch
 }
 
 // The options a call works with: read once under the engine's mutex, so that a concurrent cart_engine_set_option
@@ -257,75 +260,51 @@ int dev_alloc(T **p, size_t count) {
 // The slab workspace.  Measured on MI355X (profiles/r03_alloc.txt): the aggregation launch writes its slabs 8-9 % faster into a device
 // allocation of at most 8 GiB than into a larger one (1.41-1.43 against 1.53-1.55 ms per 16 pairs at 1242x375 D=128 P=8; the L2's write
 // requests to the fabric stall 20-30x as often in the larger one; TLB counters and clock are the same) -- whatever the physical layout
-// rule behind it, it goes by the size of the PHYSICAL allocation.  So a workspace above that size is one reserved address range (the
-// kernels keep their "base + frame stride" addressing) backed by separate physical allocations of <= kSlabChunkBytes each.
+// rule behind it, it goes by the size of the PHYSICAL allocation.  So the workspace is cut into groups of slots, each group one plain
+// hipMalloc of at most kSlabChunkBytes (a single slot larger than that gets an allocation of its own).  Round 3 kept one address range
+// and backed it with several hipMemCreate / hipMemMap allocations instead; that path met two behaviours of ROCm 7.2's virtual-memory
+// management that end in GPU memory access faults (profiles/r04_vmm_faults.txt: a hipMemSetAccess per mapping returns success and leaves
+// the range inaccessible; a range re-reserved while other ranges are live did the same) and is gone: nothing in the engine calls
+// hipMemAddressReserve / hipMemMap any more.
 constexpr size_t kSlabChunkBytes = ((size_t)8 << 30) - ((size_t)64 << 20);
 
-void slab_free(SlabSet &ss) {
-    if (!ss.base) return;
-    if (ss.reserved) {
-        size_t off = 0;
-        for (auto &h : ss.chunks) {   // one unmap per mapping, with the mapping's own size
-            const size_t sz = std::min(ss.chunk_bytes, ss.reserved - off);
-            (void)hipMemUnmap(ss.base + off, sz);
-            (void)hipMemRelease(h);
-            off += sz;
-        }
-        (void)hipMemAddressFree(ss.base, ss.reserved);
-    } else {
-        (void)hipFree(ss.base);
-    }
-    ss = SlabSet{};
+void slab_pool_free(SlabPool &sp) {
+    for (uint8_t *b : sp.base)
+        if (b) (void)hipFree(b);
+    sp = SlabPool{};
 }
 
-int slab_alloc(SlabSet &ss, int device_id, size_t bytes, size_t chunk_bytes) {
-    ss = SlabSet{};
-    if (bytes <= chunk_bytes) return dev_alloc(&ss.base, bytes);
-    hipMemAllocationProp prop{};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device_id;
-    size_t gran = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
-        (void)hipGetLastError();
-        return dev_alloc(&ss.base, bytes);   // no virtual memory management on this device: one allocation
-    }
-    const size_t chunk = std::max(gran, chunk_bytes / gran * gran), total = (bytes + gran - 1) / gran * gran;
-    void *base = nullptr;
-    if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return dev_alloc(&ss.base, bytes);
-    }
-    ss.base = static_cast<uint8_t *>(base);
-    ss.reserved = total;
-    ss.chunk_bytes = chunk;
-    size_t mapped = 0;
-    hipError_t err = hipSuccess;
-    for (size_t off = 0; off < total && err == hipSuccess; off += chunk) {
-        const size_t sz = std::min(chunk, total - off);
-        hipMemGenericAllocationHandle_t h;
-        err = hipMemCreate(&h, sz, &prop, 0);
-        if (err != hipSuccess) break;
-        ss.chunks.push_back(h);
-        err = hipMemMap(ss.base + off, sz, 0, h, 0);
-        if (err != hipSuccess) break;
-        mapped = off + sz;
-    }
-    if (err == hipSuccess) {   // ONE call over the whole range: on ROCm 7.2 a hipMemSetAccess per mapping leaves the range inaccessible
-        hipMemAccessDesc acc{};   // (memory access fault on first touch; profiles/tools/vmm_test.hip)
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        err = hipMemSetAccess(ss.base, total, &acc, 1);
-    }
-    if (err != hipSuccess) {
-        for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(ss.base + off, std::min(chunk, total - off));
-        for (auto &h : ss.chunks) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(ss.base, total);
-        ss = SlabSet{};
-        (void)hipGetLastError();
-        return dev_alloc(&ss.base, bytes);   // whatever failed: one plain allocation still gives a working (slower) workspace
+// slots per group: as many as fit kSlabChunkBytes; from 16 up a multiple of kLaunchFrames, so that the default launch sequences of a
+// call whose lease starts on a multiple of 16 stay inside one group
+int slab_group_slots(size_t slot_bytes, int slots) {
+    size_t g = std::max<size_t>(1, kSlabChunkBytes / std::max<size_t>(1, slot_bytes));
+    if (g >= (size_t)kLaunchFrames) g = g / kLaunchFrames * kLaunchFrames;
+    return (int)std::min<size_t>(g, (size_t)slots);
+}
+
+int slab_pool_alloc(SlabPool &sp, size_t slot_bytes, int slots) {
+    sp = SlabPool{};
+    sp.slot_bytes = slot_bytes;
+    sp.slots = slots;
+    sp.group_slots = slab_group_slots(slot_bytes, slots);
+    const int ng = (slots + sp.group_slots - 1) / sp.group_slots;
+    for (int gi = 0; gi < ng; ++gi) {
+        uint8_t *b = nullptr;
+        if (dev_alloc(&b, sp.bytes_of(gi))) { slab_pool_free(sp); return -1; }
+        sp.base.push_back(b);
     }
     return 0;
+}
+
+// slab pointers of the n frames of one launch at slots [s0, s0 + n); `subst` (may be null) replaces the base of some groups (placement probes)
+SlabTable slab_table(const SlabPool &sp, int s0, int n, const std::vector<uint8_t *> *subst = nullptr) {
+    SlabTable t{};
+    for (int f = 0; f < n && f < kMaxLaunchFrames; ++f) {
+        const int s = s0 + f, gi = s / sp.group_slots;
+        uint8_t *b = subst && (*subst)[gi] ? (*subst)[gi] : sp.base[gi];
+        t.frame[f] = b + (size_t)(s % sp.group_slots) * sp.slot_bytes;
+    }
+    return t;
 }
 
 }  // namespace
@@ -346,18 +325,6 @@ void cart_engine_default_params(cart_engine_params *p) {
     p->max_inflight = 12;       // CARTSLAM_CONCURRENT_RUN_LIMIT, cartslam.hpp:4
 }
 
-#ifdef CART_EXPERIMENTS
-extern "C" const void *cart_debug_slab_base(const cart_engine *e) { return e ? e->slabs : nullptr; }
-// placement study: with CART_SLAB_SLACK_MIB set at create the slab allocation has that much room behind it, and the slabs can be moved inside
-// it (idle engine): same physical allocation, another offset
-extern "C" int cart_debug_set_slab_shift(cart_engine *e, size_t bytes) {
-    if (!e || (bytes & 255) || bytes > e->slab_slack) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    e->slabs = e->slab_set.base + bytes;
-    return 0;
-}
-#endif
-
 int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     if (!out) return fail("out is NULL");
     *out = nullptr;
@@ -377,9 +344,6 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     g.npx = (size_t)g.w * g.h;
     g.census_elems = (size_t)g.h * g.cpitch;
     g.slab_bytes = g.npx * g.D;
-#ifdef CART_EXPERIMENTS   // address-mapping experiments: distance between the slabs of two paths
-    if (const char *pad = std::getenv("CART_SLAB_PAD")) g.slab_bytes += (std::strtoul(pad, nullptr, 0) + 255) & ~(size_t)255;
-#endif
     e->uniq = (float)(100 - params->uniqueness_ratio) / 100.0f;  // oracle S5
     const size_t n = (size_t)params->max_inflight;
     int rc = 0;
@@ -403,18 +367,7 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     e->cen_slack = (size_t)4 * g.cpitch + g.h + 1024;
     rc |= dev_alloc(&e->cen_l_alloc, n * g.census_elems + 2 * e->cen_slack);
     rc |= dev_alloc(&e->cen_r_alloc, n * g.census_elems + 2 * e->cen_slack);
-    e->slab_bytes_total = n * g.P * g.slab_bytes;
-#ifdef CART_EXPERIMENTS   // address-mapping experiments: CART_SLAB_CHUNK_MIB = 0: one hipMalloc whatever the size; else that chunk size
-    if (const char *sk = std::getenv("CART_SLAB_SLACK_MIB")) {
-        e->slab_slack = (size_t)std::strtoull(sk, nullptr, 0) << 20;
-        rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total + e->slab_slack, kSlabChunkBytes);
-    } else if (const char *ck = std::getenv("CART_SLAB_CHUNK_MIB")) {
-        const size_t mib = std::strtoull(ck, nullptr, 0);
-        rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total, mib ? mib << 20 : ~(size_t)0);
-    } else
-#endif
-    rc |= slab_alloc(e->slab_set, e->params.device_id, e->slab_bytes_total, kSlabChunkBytes);
-    e->slabs = e->slab_set.base;
+    rc |= slab_pool_alloc(e->slab_pool, (size_t)g.P * g.slab_bytes, (int)n);
     rc |= dev_alloc(&e->wta_l, n * g.npx);
     rc |= dev_alloc(&e->right_pk, n * g.npx);
     rc |= dev_alloc(&e->tmp_a, n * g.npx);
@@ -459,7 +412,7 @@ void cart_engine_destroy(cart_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
-    slab_free(e->slab_set);
+    slab_pool_free(e->slab_pool);
     void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
                     e->pair_xch, e->pair_ticket, e->dev_status, e->uniq_thr};
     for (void *b : bufs)
@@ -536,12 +489,11 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
 }
 
 namespace {
-// Time of the aggregation + WTA launches of `n` frames at slots [s0, s0 + n) with the slab workspace at `slabs` (ms, best of two after one
+// Time of the aggregation + WTA launches of `n` frames at slots [s0, s0 + n) with their slabs at `slabs` (ms, best of two after one
 // warm-up; the census planes hold whatever they hold: the cost of these launches does not depend on the data).  < 0 on error.
-float probe_placement(cart_engine *e, const Options &opt, uint8_t *slabs_base, size_t s0, int n, hipEvent_t ev0, hipEvent_t ev1) {
+float probe_placement(cart_engine *e, const Options &opt, const SlabTable &slabs, size_t s0, int n, hipEvent_t ev0, hipEvent_t ev1) {
     const Geometry &g = e->g;
     uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
-    uint8_t *slabs = slabs_base + s0 * g.P * g.slab_bytes;
     uint16_t *wl = e->wta_l + s0 * g.npx;
     uint32_t *rpk = e->right_pk + s0 * g.npx;
     const bool fused = plan_for(e, opt, n) == CART_PLAN_FUSED_UP && e->rv_partial;
@@ -552,30 +504,18 @@ float probe_placement(cart_engine *e, const Options &opt, uint8_t *slabs_base, s
         AggArgs a = fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, nullptr);
-#ifdef CART_EXPERIMENTS   // the two launches timed apart (stderr), for the placement study
-        hipEvent_t evm = nullptr;
-        if (rep == 2 && hipEventCreate(&evm) == hipSuccess) (void)hipEventRecord(evm, nullptr);
-#endif
         if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, nullptr);
         else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, nullptr, false);
         if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) return -1.f;
-#ifdef CART_EXPERIMENTS
-        if (evm) {
-            float ma = 0.f;
-            (void)hipEventElapsedTime(&ma, ev0, evm);
-            std::fprintf(stderr, "probe slots %zu..: aggregate %.4f wta %.4f\n", s0, ma, ms - ma);
-            (void)hipEventDestroy(evm);
-        }
-#endif
         if (rep && (best < 0.f || ms < best)) best = ms;
     }
     return best;
 }
 }  // namespace
 
-int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, float *ms_first, float *ms_kept) {
+int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size_t max_extra_bytes, float *ms_first, float *ms_kept) {
     if (!e) return fail("engine is NULL");
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (n_frames < 1 || n_frames > (int)e->slots.size()) return fail("n_frames must be in [1, max_inflight]");
@@ -593,55 +533,82 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, floa
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     HIP_TRY(hipEventCreate(&ev0));
     if (hipEventCreate(&ev1) != hipSuccess) { (void)hipEventDestroy(ev0); return fail("hipEventCreate failed"); }
-    // Every full group of n slots is probed (at most four groups): a caller with several calls in flight uses them all.  Leases are
-    // first-fit (acquire), so the lowest group carries most calls -- all of them for a caller with one call in flight: it counts three times.
-    const int groups = std::max(1, std::min(4, (int)e->slots.size() / n));
-    auto score = [&](uint8_t *base) {
-        float sum = 0.f;
-        for (int gi = 0; gi < groups; ++gi) {
-            const float t = probe_placement(e, opt, base, (size_t)gi * n, n, ev0, ev1);
-            if (t < 0.f) return -1.f;
-            sum += gi == 0 ? 3.f * t : t;
-        }
-        return sum / (groups + 2);
-    };
+    SlabPool &sp = e->slab_pool;
+    // The search runs per UNIT = the groups behind the slots [k n, (k + 1) n) of one n-frame call, for the first (at most four) such
+    // ranges: a lease takes the lowest free range its stream used last (acquire), so a caller with one call in flight lives in unit 0
+    // and one with several walks up the units.  A group already settled by an earlier unit is not touched again.
+    const int units = std::max(1, std::min(4, (int)e->slots.size() / n));
+    std::vector<char> settled((size_t)sp.groups(), 0);
+    // Candidates that lost stay allocated while the search goes on (freed at once, their pages would come straight back from the
+    // allocator), oldest first out when the byte cap is reached; everything is plain hipMalloc / hipFree.
+    struct Held { uint8_t *p; size_t bytes; };
+    std::vector<Held> held;
+    size_t extra = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    float kept = score(e->slab_set.base);
-    if (ms_first) *ms_first = kept;
-    float worst = kept;
-    std::vector<SlabSet> losers;   // all stay allocated until the end (the free-memory check below bounds them): a placement freed at once
-                                   // would be handed out again, and address ranges recycled while others are live have faulted on ROCm 7.2
-    int rc = 0;
-    for (int t = 1; t < max_tries && kept >= 0.f; ++t) {
-        // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
-        // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
-        // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 1.5 s + 1 s per 20 GB of workspace in all.
-        if (kept < 0.885f * worst) break;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5 + (double)e->slab_bytes_total / 20e9) break;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < e->slab_bytes_total + ((size_t)4 << 30)) break;   // no room for another candidate
-        SlabSet cand;
-        if (slab_alloc(cand, e->params.device_id, e->slab_bytes_total, kSlabChunkBytes)) { (void)hipGetLastError(); break; }
-        const float sc = score(cand.base);
-#ifdef CART_EXPERIMENTS
-        std::fprintf(stderr, "tune_placement: try %d  %.4f ms (kept so far %.4f)\n", t, sc, kept);
-#endif
-        if (sc < 0.f) { slab_free(cand); rc = fail("placement probe failed"); break; }
-        worst = std::max(worst, sc);
-        if (sc < kept) {
-            losers.push_back(std::move(e->slab_set));
-            e->slab_set = std::move(cand);
-            e->slabs = e->slab_set.base;
-            kept = sc;
-        } else {
-            losers.push_back(std::move(cand));
+    double sum_first = 0.0, sum_kept = 0.0;
+    int rc = 0, probed = 0;
+    for (int u = 0; u < units && rc == 0; ++u) {
+        const int s0 = u * n, g0 = s0 / sp.group_slots, g1 = (s0 + n - 1) / sp.group_slots;
+        std::vector<int> mine;
+        size_t unit_bytes = 0;
+        for (int gi = g0; gi <= g1; ++gi)
+            if (!settled[(size_t)gi]) { mine.push_back(gi); unit_bytes += sp.bytes_of(gi); settled[(size_t)gi] = 1; }
+        float kept = probe_placement(e, opt, slab_table(sp, s0, n), (size_t)s0, n, ev0, ev1);
+        if (kept < 0.f) { rc = fail("placement probe failed"); break; }
+        sum_first += kept;
+        ++probed;
+        float worst = kept;
+        // at most this many bytes beyond the workspace at any time (0 = two units' worth); SIZE_MAX = whatever leaves 4 GiB free
+        const size_t cap = max_extra_bytes ? max_extra_bytes : 2 * unit_bytes;
+        for (int t = 1; t < max_tries && !mine.empty(); ++t) {
+            // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
+            // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
+            // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 1.5 s + 1 s per 20 GB of workspace in all.
+            if (kept < 0.885f * worst) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5 + (double)sp.slots * (double)sp.slot_bytes / 20e9) break;
+            while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
+                (void)hipFree(held.front().p);
+                extra -= held.front().bytes;
+                held.erase(held.begin());
+            }
+            if (extra + unit_bytes > cap) break;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < unit_bytes + ((size_t)4 << 30)) break;   // no room for another candidate
+            std::vector<uint8_t *> cand((size_t)sp.groups(), nullptr);
+            bool ok = true;
+            for (int gi : mine)
+                if (dev_alloc(&cand[(size_t)gi], sp.bytes_of(gi))) { ok = false; break; }
+            if (!ok) {
+                (void)hipGetLastError();
+                for (int gi : mine) if (cand[(size_t)gi]) (void)hipFree(cand[(size_t)gi]);
+                break;
+            }
+            extra += unit_bytes;
+            const float sc = probe_placement(e, opt, slab_table(sp, s0, n, &cand), (size_t)s0, n, ev0, ev1);
+            if (sc < 0.f) {
+                for (int gi : mine) (void)hipFree(cand[(size_t)gi]);
+                extra -= unit_bytes;
+                rc = fail("placement probe failed");
+                break;
+            }
+            worst = std::max(worst, sc);
+            const bool better = sc < kept;
+            for (int gi : mine) {   // the loser of every group joins the held list
+                uint8_t *lose = better ? sp.base[(size_t)gi] : cand[(size_t)gi];
+                if (better) sp.base[(size_t)gi] = cand[(size_t)gi];
+                held.push_back(Held{lose, sp.bytes_of(gi)});
+            }
+            if (better) kept = sc;
         }
+        sum_kept += kept;
     }
     (void)hipDeviceSynchronize();
-    for (auto &l : losers) slab_free(l);
+    for (auto &h : held) (void)hipFree(h.p);
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    if (kept < 0.f && rc == 0) rc = fail("placement probe failed");
-    if (ms_kept) *ms_kept = kept;
+    if (probed && rc == 0) {   // mean over the probed units, before and after
+        if (ms_first) *ms_first = (float)(sum_first / probed);
+        if (ms_kept) *ms_kept = (float)(sum_kept / probed);
+    }
     return rc;
 }
 
@@ -772,7 +739,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         const size_t s0 = (size_t)l.s0 + f0;
         uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
         uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
-        uint8_t *slabs = e->slabs + s0 * g.P * g.slab_bytes;
+        const SlabTable slabs = slab_table(e->slab_pool, (int)s0, n);
         uint16_t *wl = e->wta_l + s0 * g.npx;
         uint32_t *rpk = e->right_pk + s0 * g.npx;
         int16_t *ta = e->tmp_a + s0 * g.npx, *tb = e->tmp_b + s0 * g.npx;
@@ -1536,7 +1503,7 @@ int cart_debug_read(cart_engine *e, int frame_slot, int what, void *host_dst, si
         if (bytes < need) return fail("buffer too small");
         HIP_TRY(hipMemcpy2D(host_dst, (size_t)g.w * 4, c, (size_t)g.cpitch * 4, (size_t)g.w * 4, g.h, hipMemcpyDeviceToHost));
     } else if (what >= CART_DBG_PATH0 && what < CART_DBG_PATH0 + g.P) {
-        src = e->slabs + ((size_t)slot * g.P + (what - CART_DBG_PATH0)) * g.slab_bytes; need = g.npx * g.D;   // slab_bytes is the stride
+        src = e->slab_pool.slot_ptr(slot) + (size_t)(what - CART_DBG_PATH0) * g.slab_bytes; need = g.npx * g.D;
         if (bytes < need) return fail("buffer too small");
         std::vector<uint8_t> raw(need);
         HIP_TRY(hipMemcpy(raw.data(), src, need, hipMemcpyDeviceToHost));

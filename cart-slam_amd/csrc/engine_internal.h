@@ -37,9 +37,15 @@ struct DirDesc {
     int path;     // slab index (oracle order: down, up, right, left, diagonals)
 };
 
+// Where the cost slabs of the frames of ONE launch live: frame f's P path slabs are frame[f] + path * slab_bytes, each [h][w][D].
+// The slab workspace is a set of separate device allocations of at most 8 GiB (cart_engine.hip, SlabPool), so the frames of a
+// launch need not be one address range; every SGM kernel takes this table by value (wave-uniform index: one scalar load).
+constexpr int kMaxLaunchFrames = 64;   // upper bound of CART_OPT_CHUNK_FRAMES
+struct SlabTable { uint8_t *frame[kMaxLaunchFrames]; };
+
 struct AggArgs {
     const uint32_t *cen_l, *cen_r;   // slot 0 of the lease
-    uint8_t *slabs;                  // [slot][path][h][w][D]
+    SlabTable slabs;                 // per frame of the launch: [path][h][w][D]
     Geometry g;
     int ndirs;
     int blocks_per_frame;
@@ -80,13 +86,13 @@ int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is 
 int agg_residency_cap(int ndirs, int D, int n_frames);  // 4-wave aggregation workgroups allowed per CU at a time, 0 = uncapped (measured table at its definition)
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 // thr = device table of the integer uniqueness threshold for every best cost 0..2047 (launch_uniq_table, built once per engine)
-void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
+void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s, bool top2 = false);   // top2: the S5 variant (second-best only), two-kernel WTA only
 // plan PAIRS (sgm_kernels.hip): one sweep per vertical direction carries that direction and the diagonal leaning the same way
 size_t pair_xch_elems(const Geometry &g);   // 8-byte words of the per-frame hand-over buffer
-void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
+void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
                        const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s);
-void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
+void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
                       const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
 // The sweep addresses its slab stores as "wave-uniform base + 32-bit lane offset"; lanes of columns >= w are sent to the
 // same cell of the sink slab, (sink - out) <= 4 slabs further on.  That offset plus one image row of columns has to fit 32
@@ -95,7 +101,7 @@ inline bool pairs_offsets_fit(const Geometry &g) { return 4 * (unsigned long lon
 // WTA fused with the "up" direction (slab kFusedUpPath is never read: the aggregate launch may skip that direction)
 constexpr int kFusedUpPath = 1;
 size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer
-void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
+void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
 void launch_uniq_table(float u, uint16_t *out_dev, hipStream_t s);   // test access to the integer uniqueness threshold
 void uniq_table_host(float u, uint16_t *out);

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
         // uniform bases + non-negative per-lane element offsets
         const uint32_t *pl_u = a.cen_l + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x);
         const uint32_t *pr_u = a.cen_r + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0r * g.cpitch + g.cpadl + x - g.min_disp - (WN::D - 1));
-        uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0r * g.w + x) * g.D);
+        uint8_t *po_u = a.slabs.frame[frame] + uniform((ptrdiff_t)a.dirs[di].path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0r * g.w + x) * g.D);
         unsigned lo_l = (unsigned)pg * g.cpitch * 4u, lo_r = lo_l + (unsigned)(WN::D - 16 - d0) * 4u;  // bytes
         unsigned lo_o = (unsigned)pg * g.w * g.D + d0;
         const ptrdiff_t cstride = dx, ostride = (ptrdiff_t)dx * g.D;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     const ptrdiff_t cen_off = (ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)ys * g.cpitch + g.cpadl + jf;
     const uint32_t *pw_base = a.cen_r + uniform(cen_off - g.min_disp - (WN::D - 1));  // window start at t = 0
     const uint32_t *pl_u = a.cen_l + uniform(cen_off);
-    uint8_t *po_u = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.dirs[di].path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + jf) * g.D);
+    uint8_t *po_u = a.slabs.frame[frame] + uniform((ptrdiff_t)a.dirs[di].path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + jf) * g.D);
     unsigned lo_l = (unsigned)pgv * 4u, lo_o = (unsigned)(pgv * WN::D + d0);  // bytes
 
     // ragged start / end of diagonal lines (and waves with invalid lines): simple, fully synchronous steps
@@ -823,7 +823,7 @@ template <int LPP> constexpr int pair_cols() { return kPairWaves * (64 / LPP); }
 
 struct PairArgs {
     const uint32_t *cen_l, *cen_r;
-    uint8_t *slabs;                // [frame][path][h][w][D]
+    SlabTable slabs;               // per frame: [path][h][w][D]
     unsigned long long *xch;       // [frame][blk][row][LPP][5] {payload, epoch}
     uint32_t *ticket;              // one counter per launch (reset by the block that draws the last ticket)
     uint32_t *status;              // device status word: non-zero after a hand-over timeout
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
     // image store into the same cell of a slab this plan never reads.  The sink offset is a 32-bit lane offset: the
     // engine only takes this plan when pairs_offsets_fit(g) (engine_internal.h), i.e. 4 slabs + a row stay below 2^32
     const int xbase = min(xw0, g.w - 1), xc = min(x, g.w - 1);
-    uint8_t *po = a.slabs + uniform((ptrdiff_t)(frame * g.P + a.out_path) * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + xbase) * D);
+    uint8_t *po = a.slabs.frame[frame] + uniform((ptrdiff_t)a.out_path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + xbase) * D);
     unsigned lo_l = (unsigned)pg * 4u;
     unsigned lo_o = (unsigned)((xc - xbase) * D + d0) + (valid ? 0u : (unsigned)(a.sink_path - a.out_path) * (unsigned)g.slab_bytes);
 
@@ -1027,7 +1027,7 @@ size_t pair_xch_elems(const Geometry &g) {   // 8-byte words per frame
     return (size_t)((g.w + cols - 1) / cols) * g.h * lpp * 5;
 }
 
-void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, uint8_t *slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
+void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
                        const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s) {
     const int lpp = g.D / 16, cols = kPairWaves * (64 / lpp);
     PairArgs a{cen_l, cen_r, slabs, xch, ticket, status, g, epoch, out_path, sink_path, (g.w + cols - 1) / cols};
@@ -1121,7 +1121,7 @@ void uniq_table_host(float u, uint16_t *out) {
 // right-census window is staged in LDS once per block, a lane reads its 16 features from there (the kernel is bound by
 // the slab reads: the ~50 extra VALU operations per lane and pass are free).
 struct WtaArgs {
-    const uint8_t *slabs;
+    SlabTable slabs;
     const uint32_t *cen_l, *cen_r;   // PAIRS only
     uint16_t *wta_l;
     uint32_t *right_pk;
@@ -1145,11 +1145,11 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     constexpr int DP = D + 8;                 // LDS row pitch in u16: 16 B of padding spread the pixels' rows over the banks
     constexpr int PPP = 256 / LPP;            // pixels per pass
     constexpr int NPASS = kWtaTileX / PPP;    // 1 (D=64), 2 (D=128), 4 (D=256)
-    const uint8_t *slabs = a.slabs;
     uint16_t *wta_l = a.wta_l;
     uint32_t *right_pk = a.right_pk;
     const Geometry &g = a.g;
     const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;
+    const uint8_t *slabs = a.slabs.frame[frame];   // this frame's path slabs
     const int grp = threadIdx.x / LPP, gl = threadIdx.x % LPP, d0 = gl * 16;
     // Right view: every lane min-reduces its 16 (S << 16 | d) keys into the tile's array indexed by p = x - d (ds_min_u32),
     // slot p - (x0 - (D-1)).  (Walking the tile's diagonals per right pixel instead -- 64 dependent LDS reads on 127 of
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     auto issue_pass = [&](int pass, v4u (&dst)[PREFETCH ? kMaxPaths : 1]) {
         if constexpr (PREFETCH) {
             const int xcp = min(x0 + pass * PPP + grp, g.w - 1);
-            const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xcp) * D + d0;
+            const uint8_t *p = slabs + ((size_t)y * g.w + xcp) * D + d0;
 #pragma unroll
             for (int r = 0; r < kMaxPaths; ++r)
                 if (r < a.nslabs) dst[r] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)a.slab_idx[r] * g.slab_bytes));
@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
                 }
             }
         } else {
-            const uint8_t *p = slabs + ((size_t)frame * g.P * g.npx + (size_t)y * g.w + xc) * D + d0;
+            const uint8_t *p = slabs + ((size_t)y * g.w + xc) * D + d0;
             for (int r = 0; r < a.nslabs; ++r) {
                 const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + (size_t)a.slab_idx[r] * g.slab_bytes));
 #pragma unroll
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     }
 }
 
-void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
+void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s, bool top2) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
@@ -1337,7 +1337,7 @@ void launch_wta(const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk, const
 }
 
 // plan PAIRS: slabs 0 / 1 = pair sums {down, down-right} / {up, up-right}, slabs 2, 3, 5, 6 = right, left, down-left, up-left
-void launch_wta_pairs(const uint8_t *slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
+void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
                       const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
@@ -1390,7 +1390,7 @@ inline int fused_waves_for(const Geometry &g) { return g.D >= 256 && g.w >= 1600
 
 struct FusedArgs {
     const uint32_t *cen_l, *cen_r;
-    const uint8_t *slabs;
+    SlabTable slabs;
     uint16_t *wta_l;
     uint32_t *partial;   // [frame][block][sweep step][rv_row_slots] u16 right-view minima of every block (rv_key16; last slot of a row: unused sink)
     Geometry g;
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     const uint32_t *pl0 = a.cen_l + uniform(cen0);
     unsigned lo_l = (unsigned)pg * 4u;
     const int xbase = min(xw0, g.w - 1), xc = min(x, g.w - 1);   // xbase <= xc
-    const uint8_t *ps0 = a.slabs + uniform((ptrdiff_t)frame * g.P * (ptrdiff_t)g.slab_bytes + (ptrdiff_t)xbase * D);
+    const uint8_t *ps0 = a.slabs.frame[frame] + uniform((ptrdiff_t)xbase * D);
     unsigned lo_s = (unsigned)((xc - xbase) * D + d0);
     const ptrdiff_t row_bytes = (ptrdiff_t)g.w * D;
 
@@ -1712,7 +1712,7 @@ size_t wta_fused_partial_elems(const Geometry &g) {
     return (size_t)hpad * ((g.w + cols - 1) / cols) * (rv_row_slots(cols, g.D, fused_rv_padded(g)) / 2);   // u32 elements of u16 keys
 }
 
-void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const uint8_t *slabs, uint16_t *wta_l, uint32_t *right_pk,
+void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk,
                       uint32_t *partial, const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s) {
     FusedArgs a{cen_l, cen_r, slabs, wta_l, partial, g, thr, xcd_placement(g, n_frames) ? 1 : 0};
     const int wpb = fused_waves_for(g), cols = wpb * (64 / (g.D / 16));

@@ -25,7 +25,10 @@ class FrameSharder {
    public:
     // devices: HIP device ids, devices[0] holds the sequence and receives the results.  params.max_inflight is overwritten.
     // framesPerGpu: the largest share of one sequence a GPU may hold (capacity() = framesPerGpu * gpus()).
-    FrameSharder(const std::vector<int> &devices, cart_engine_params params, int framesPerGpu, int updateInterval = 30, int resetInterval = 10);
+    // placementTries > 1 opts in to cart_engine_tune_placement on every GPU's engine (set-up time and, transiently, up to two units
+    // of slab memory per GPU beyond the workspace: include/cart_engine.h); the default keeps the engines' first allocations.
+    FrameSharder(const std::vector<int> &devices, cart_engine_params params, int framesPerGpu, int updateInterval = 30, int resetInterval = 10,
+                 int placementTries = 1);
     ~FrameSharder();
     FrameSharder(const FrameSharder &) = delete;
     FrameSharder &operator=(const FrameSharder &) = delete;

@@ -68,10 +68,13 @@ struct ScopedStream {
     void wait() { hipCheck(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 };
 
-// CARTSLAM_PLACEMENT_TRIES = placements of the slab workspace cart_engine_tune_placement may try (default 10, it stops at the first fast one; 1 = keep the first)
+// CARTSLAM_PLACEMENT_TRIES = placements of the slab workspace cart_engine_tune_placement may try.  Default 1 = keep the allocation the
+// engine was created with: a module constructor does not go looking for device memory on its own.  A deployment that wants the 2-4 %
+// (include/cart_engine.h) sets it to 2..10; the search then holds at most two units of slab memory beyond the workspace (the call's
+// default cap) and logs what it found.
 int placementTries() {
     const char *env = std::getenv("CARTSLAM_PLACEMENT_TRIES");
-    return env ? std::max(1, std::atoi(env)) : 10;
+    return env ? std::max(1, std::atoi(env)) : 1;
 }
 
 cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int radius, int iterations, int paths, int p1, int p2, int uniq) {
@@ -87,10 +90,15 @@ cart_engine_params paramsFor(Size res, int minDisparity, int numDisparities, int
 
 EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
     if (cart_engine_create(&params, &engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
-    // Pick the fastest of a few physical placements of the cost-slab workspace (include/cart_engine.h, cart_engine_tune_placement: the
-    // aggregation launch runs 8-9 % faster on some; 0.03-0.2 s once per module, seconds when the allocator is slow).  Not fatal: a failed probe leaves the first placement.
-    if (params.num_disparities > 0 && placementTries() > 1)
-        (void)cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), nullptr, nullptr);
+    // Opt-in (CARTSLAM_PLACEMENT_TRIES > 1): pick the fastest of a few physical placements of the cost-slab workspace (include/cart_engine.h,
+    // cart_engine_tune_placement: the aggregation launch runs 8-9 % faster on some).  Not fatal: a failed probe leaves the first placement.
+    if (params.num_disparities > 0 && placementTries() > 1) {
+        float first = 0.f, kept = 0.f;
+        if (cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), /*max_extra_bytes: default cap*/ 0, &first, &kept) != 0)
+            std::fprintf(stderr, "[cartslam_amd] placement tuning failed (%s); keeping the first placement\n", cart_last_error(engine));
+        else
+            std::fprintf(stderr, "[cartslam_amd] placement tuning: launch pair %.3f -> %.3f ms\n", first, kept);
+    }
 }
 EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }
 void EngineHandle::fail(const char *what) const { throw std::runtime_error(std::string(what) + ": " + cart_last_error(engine)); }

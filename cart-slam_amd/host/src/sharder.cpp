@@ -1,5 +1,6 @@
 #include "cartslam_amd/sharder.hpp"
 
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -85,7 +86,7 @@ struct FrameSharder::Rank {
     }
 };
 
-FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params params, int framesPerGpu, int updateInterval, int resetInterval)
+FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params params, int framesPerGpu, int updateInterval, int resetInterval, int placementTries)
     : framesPerGpu(framesPerGpu), width(params.width), height(params.height) {
     if (devices.empty() || framesPerGpu < 1) throw std::invalid_argument("FrameSharder needs at least one GPU and one frame per GPU");
     const int n = (int)devices.size();
@@ -102,7 +103,8 @@ FrameSharder::FrameSharder(const std::vector<int> &devices, cart_engine_params p
         params.device_id = devices[r];
         params.max_inflight = framesPerGpu;
         if (cart_engine_create(&params, &rank->engine) != 0) throw std::runtime_error(std::string("cart_engine_create: ") + cart_last_error(nullptr));
-        (void)cart_engine_tune_placement(rank->engine, std::min(framesPerGpu, 16), 10, nullptr, nullptr);   // a fast slab placement among up to ten (cart_engine.h)
+        if (placementTries > 1 && cart_engine_tune_placement(rank->engine, std::min(framesPerGpu, 16), placementTries, /*default cap*/ 0, nullptr, nullptr) != 0)
+            std::fprintf(stderr, "[cartslam_amd] GPU %d: placement tuning failed (%s); keeping the first placement\n", devices[r], cart_last_error(rank->engine));
         cartOk(cart_plane_schedule_create(rank->engine, /*histogram_peak*/ 1, nullptr, updateInterval, resetInterval, &rank->schedule), rank->engine,
                "cart_plane_schedule_create");
         for (int b = 0; b < 2; ++b) {

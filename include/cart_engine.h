@@ -112,18 +112,25 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * module adapters never force a plan and need not ask. */
 int cart_engine_device_status(cart_engine *engine, unsigned *status);
 
-/* Placement tuning of the cost-slab workspace (no reference counterpart; optional).  On MI355X the time of the two slab-bound launches
- * depends on WHICH physical memory backs the slabs: the same kernels on the same addresses run in one of two modes per allocation
- * (aggregation 1.41-1.43 or 1.53-1.55 ms, WTA 1.15 or 1.27 ms per 16 pairs at 1242x375 D=128 P=8; profiles/r03_alloc.txt: the L2's write
- * requests to the fabric stall 20-30x as often in the slow mode, TLB misses and clock are the same; allocations above 8 GiB are always
- * slow, which is why the engine backs a larger workspace with several physical allocations behind one address range).  This call times
- * the aggregation + WTA launches of `n_frames` frames on the current workspace, then on up to `max_tries - 1` freshly allocated ones
- * (all of them exist until the call returns: it stops when the next one would not leave 4 GiB of device memory free, and early once
- * the kept placement is 11.5 % faster than the slowest one seen, i.e. is a fast one), keeps the fastest and frees the others.  The engine must
- * be idle; results do not change (every placement gives the same bits).  ms_first / ms_kept (may be NULL): launch-pair time over the
- * probed slot groups before and after (the lowest group, which first-fit leases use most, weighted 3 : 1).  Call it once after cart_engine_create / cart_engine_set_option when creation time does
- * not matter (about 16 ms per try at 1242x375 D=128 P=8 with 32 slots). */
-int cart_engine_tune_placement(cart_engine *engine, int n_frames, int max_tries, float *ms_first, float *ms_kept);
+/* Placement tuning of the cost-slab workspace (no reference counterpart; OPTIONAL and opt-in: nothing calls it unless the caller asks).
+ * On MI355X the time of the two slab-bound launches depends on WHICH physical memory backs the slabs: the same kernels run in one of two
+ * modes per allocation (aggregation 1.41-1.43 or 1.53-1.55 ms, WTA 1.15 or 1.27 ms per 16 pairs at 1242x375 D=128 P=8;
+ * profiles/r03_alloc.txt: the L2's write requests to the fabric stall 20-30x as often in the slow mode, TLB misses and clock are the same;
+ * allocations above 8 GiB are always slow, which is why the engine cuts its slab workspace into groups of slots, each one plain hipMalloc
+ * of at most 8 GiB - 64 MiB).
+ * The call works per UNIT = the slot groups behind slots [k n, (k+1) n) of an `n_frames` call (n = min(n_frames, frames per launch)),
+ * for the first (at most four) such ranges: it times the aggregation + WTA launches of n frames on the unit's current allocations, then on
+ * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others; it stops early once the kept set is 11.5 % faster
+ * than the slowest one seen (i.e. is a fast one) or after 1.5 s + 1 s per 20 GB of workspace.
+ * TRANSIENT FOOTPRINT: candidates that lost stay allocated while the search goes on (freed at once, the allocator would hand the same
+ * pages back); at no time does the call hold more than `max_extra_bytes` beyond the engine's own workspace -- 0 selects two units' worth
+ * (one unit = the groups of one n-frame call: 7.6 GB at 1242x375 D=128 P=8 with n = 16), SIZE_MAX lifts the cap (the search then stops
+ * when the next candidate would not leave 4 GiB of device memory free: what bench.py uses, reported as `placement_tuning`).  With a
+ * cap below one unit the call measures and returns without trying anything.  Peak device memory of the process during the call =
+ * workspace + min(max_extra_bytes, (max_tries - 1) x unit); after it, the workspace alone.
+ * The engine must be idle; results do not change (every placement gives the same bits).  ms_first / ms_kept (may be NULL): mean
+ * launch-pair time over the probed units before and after.  About 16 ms per try at 1242x375 D=128 P=8. */
+int cart_engine_tune_placement(cart_engine *engine, int n_frames, int max_tries, size_t max_extra_bytes, float *ms_first, float *ms_kept);
 
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
  * create when engine == NULL).  Never NULL. */

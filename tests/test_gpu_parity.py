@@ -1113,35 +1113,69 @@ def test_xcd_placed_launches_cover_every_frame(torch_cuda, w, h, D, P, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,P,inflight", [(128, 8, 40), (256, 4, 6), (64, 4, 8)])
-def test_placement_tuning_keeps_the_bits(torch_cuda, D, P, inflight):
-    """cart_engine_tune_placement (the slab workspace re-allocated a few times, the fastest placement kept; above 8 GiB the workspace
-    is one address range over several physical allocations) changes no result: every slot group gives the oracle's disparity before and
-    after, with every plan; the reported times are positive and the kept one is not slower than the first."""
+@pytest.mark.parametrize("D,P,inflight,cap", [(128, 8, 40, None), (256, 4, 6, 0), (64, 4, 8, 1 << 20)])
+def test_placement_tuning_keeps_the_bits(torch_cuda, D, P, inflight, cap):
+    """cart_engine_tune_placement (slot groups of the slab workspace re-allocated a few times, the fastest set kept; the workspace is one
+    plain hipMalloc per group of at most 8 GiB) changes no result: a call over EVERY slot -- launch sequences in every group, some of
+    them across a group boundary -- gives the same disparities before and after, and the oracle's; the reported times are positive
+    and the kept one is not slower than the first.  cap = max_extra_bytes: None no cap, 0 the default (two units), 1 MiB = too small
+    for any candidate (the call then only measures)."""
     torch = torch_cuda
-    w, h, B = 1242, 375, 3
-    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=inflight)   # D=128 P=8 x 40 slots = 19 GB: three physical chunks
-    ls, rs = synth.make_batch(B, w, h, D, 4, scene="stripes")
-    l, r = dev(torch, ls), dev(torch, rs)
-    want = O.disparity_module(ls[1], rs[1], D, P, 4, radius=2, iterations=1)
-    def all_groups():
-        # leases are handed out lowest-first on one stream: hold earlier outputs so that later calls move up the slots
+    w, h = 1242, 375
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=inflight)   # D=128 P=8 x 40 slots = 19 GB: groups of 16 + 16 + 8 slots
+    lsb, rsb = synth.make_batch(inflight, w, h, D, 4, scene="stripes")
+    l, r = dev(torch, lsb), dev(torch, rsb)
+    def every_slot():
+        # a lease takes the lowest free range last used on its stream (engine acquire()), so calls of a few frames on one stream
+        # never leave the first slots: one call of max_inflight frames is what reaches every slot group
         outs = []
         for plan in ("slabs", "fused_up", "auto"):
             eng.set_plan(plan)
-            outs.append(eng.compute_disparity(l, r))
+            outs.append(eng.compute_disparity(l, r).cpu().numpy())
         return outs
-    before = [o.cpu().numpy() for o in all_groups()]
-    first, kept = eng.tune_placement(B, 3)
+    before = every_slot()
+    first, kept = eng.tune_placement(min(16, inflight), 3, max_extra_bytes=cap)
     assert first > 0 and 0 < kept <= first
-    after = [o.cpu().numpy() for o in all_groups()]
+    if cap == 1 << 20:
+        assert kept == first   # nothing could be tried under a 1 MiB cap
+    after = every_slot()
     for a, b in zip(before, after):
         assert np.array_equal(a, b)
-        assert np.array_equal(a[1], want)
-    # one call over every slot: launch sequences in every physical chunk, one of them across a chunk boundary
-    lsb, rsb = synth.make_batch(inflight, w, h, D, 4)
-    eng.set_plan("auto")
-    d1 = eng.compute_disparity(dev(torch, lsb), dev(torch, rsb)).cpu().numpy()
     for f in sorted({0, inflight // 2, 17 % inflight, inflight - 1}):
-        assert np.array_equal(d1[f], O.disparity_module(lsb[f], rsb[f], D, P, 4, radius=2, iterations=1)), f
+        assert np.array_equal(after[2][f], O.disparity_module(lsb[f], rsb[f], D, P, 4, radius=2, iterations=1)), f
     eng.close()
+
+
+@pytest.mark.gpu
+def test_two_large_engines_tuned_side_by_side(torch_cuda):
+    """Round-3 hazard, made unreachable: the slab workspace used to sit behind HIP virtual-memory-management calls, and ranges that were
+    freed and re-reserved while others were live ended in GPU memory access faults (profiles/r04_vmm_faults.txt).  The workspace is plain
+    hipMalloc groups now.  The sequence that was never covered: two engines above 8 GiB alive at once, both tuned, the first tuned a
+    second time, one destroyed and a third created and tuned in its place -- every engine's call over all of its slots must give the
+    oracle's disparities at every step."""
+    torch = torch_cuda
+    w, h = 1242, 375
+    cfgs = {"a": (128, 8, 20), "b": (256, 4, 18)}   # 9.5 GB (groups of 16 + 4 slots) and 8.6 GB (16 + 2)
+    engs, data = {}, {}
+    def check(k):
+        D, P, n = cfgs[k]
+        ls, rs = data[k]
+        got = engs[k].compute_disparity(dev(torch, ls), dev(torch, rs)).cpu().numpy()
+        for f in (0, 15, 16, n - 1):   # both groups, both sides of the boundary
+            assert np.array_equal(got[f], O.disparity_module(ls[f], rs[f], D, P, 4, radius=2, iterations=1)), (k, f)
+    for k, (D, P, n) in cfgs.items():
+        engs[k] = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=n)
+        data[k] = synth.make_batch(n, w, h, D, 4, first_frame=3)
+    check("a"); check("b")
+    for k in ("a", "b"):
+        first, kept = engs[k].tune_placement(16, 3)
+        assert first > 0 and 0 < kept <= first
+    check("a"); check("b")
+    engs["a"].tune_placement(16, 4, max_extra_bytes=None)   # second search on an engine whose first search freed its losers
+    check("a"); check("b")
+    engs["b"].close()                                       # its groups go back to the allocator while "a" is live ...
+    engs["b"] = make_engine(w, h, 256, 4, 4, radius=2, iters=1, inflight=18)   # ... and come back for a new engine
+    engs["b"].tune_placement(16, 3)
+    check("b"); check("a")
+    for e in engs.values():
+        e.close()
