@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--paths", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the informational host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-bgr", action="store_true", help="skip the informational 3-channel-input leg (`value_bgr_input`: what ImageDisparityModule::runInternal is handed, disparity.cu:66-67)")
     ap.add_argument("--latency", action="store_true", help="also time ONE resident pair, host-synchronous (informational `single_pair_latency`; off by default so that "
                     "every aggregation / WTA launch of the default command is a full batch and rocprofv3 --stats averages agree with `roofline.launch_ms`)")
     ap.add_argument("--placement-tries", type=int, default=10, help="physical placements of the slab workspace the engine may try at set-up (1 = keep the first)")
@@ -339,6 +340,28 @@ def run(args, world, rank, dev_index):
         ts.sort()
         latency = {"ms": round(ts[len(ts) // 2] * 1e3, 4), "fastest_ms": round(ts[0] * 1e3, 4),
                    "what": "one resident pair through disparity + plane labelling (static parameters) + CCL, enqueue to synchronize, median of 30"}
+    # Informational (never `value`): the same step on the input the reference's module is actually handed -- 8UC3 BGR images
+    # (src/modules/disparity/disparity.cu:66-67 always converts; CARTSLAM_IMAGE_MAKE_GRAYSCALE is never defined).  The BGR->gray
+    # conversion is fused into the census kernel's tile load, so the step reads 6 instead of 2 input bytes per pixel (0.4 % of
+    # B_alg).  The frames are the gray frames replicated into three channels: (1868 + 9617 + 4899) g + 8192 >> 14 == g, so the
+    # disparities must equal the gray run's bit for bit, which is checked.
+    bgr = None
+    if world == 1 and not args.no_bgr:   # one rank only: a step of the sharded pipeline is a collective
+        l3 = left.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+        r3 = right.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+        torch.cuda.synchronize()
+        ready3 = torch.cuda.current_stream().record_event()
+        n_bgr = max(4, min(args.steps, 20))
+        for _ in range(8):
+            o3 = pipe.process_batch(l3, r3, inputs_ready=ready3)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(n_bgr):
+            o3 = pipe.process_batch(l3, r3, inputs_ready=ready3)
+        torch.cuda.synchronize()
+        bgr = {"pairs_per_s": round(B * n_bgr / (time.perf_counter() - tb), 1), "steps": n_bgr, "input": "8UC3 BGR (gray replicated), resident in HBM",
+               "disparity_equals_gray_run": bool(torch.equal(o3["disparity"], last["disparity"]))}
+        del l3, r3, o3
     pcie = None
     if world == 1 and not args.no_pcie:
         # Informational (never `value`): the same step when the caller hands over HOST buffers -- H2D of the 16 pairs
@@ -494,14 +517,14 @@ def run(args, world, rank, dev_index):
                          "frac_basis": "SURVEY 8d table bytes: all P slabs written and read once",
                          "alg_bytes_per_launch": agg_bytes, "frames_per_launch": fpl, "launch_ms": round(roof_ms, 4),
                          "launches_timed": ncalls,
-                         # bytes the launch plan really has to move (equal to the table's for plan slabs); the copy-ceiling
-                         # fraction is priced with these, so a plan that skips slabs cannot print more than 1
+                         # bytes the launch plan really has to move (equal to the table's for plan slabs); frac_moved and the ratio
+                         # to the copy rate are priced with these, so a plan that skips slabs is not credited with bytes it never moved
                          "moved_bytes_per_launch": moved_bytes, "frac_moved": round(moved_gbps / HBM_PEAK_GBS, 4),
                          # device-to-device copy of 2 GiB on this box, bytes read + written per second: a reference rate, not a bound --
                          # half of a copy is reads; the aggregation launch is nine tenths writes and on a good placement of its slabs
                          # (placement_tuning) moves its bytes 4-15 % faster than the copy does (write-only stream: 5.7 TB/s)
-                         "copy_ceiling_GBps": round(copy_gbps, 1) if copy_gbps else None,
-                         "frac_of_copy_ceiling": round(moved_gbps / copy_gbps, 4) if copy_gbps else None},
+                         "copy_rate_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                         "ratio_to_copy_rate": round(moved_gbps / copy_gbps, 4) if copy_gbps else None},
             "stages_ms_per_launch": {k: round(v, 4) for k, v in stages.items()},
             "job_alg_GBps": round(alg_bytes_per_pair(w, h, D, P) * value / 1e9, 1),
             "device_ms_per_pair_disparity": round(device_ms_per_pair, 4) if device_ms_per_pair else None,
@@ -509,15 +532,14 @@ def run(args, world, rank, dev_index):
         vi = measured_traffic("aggregate", "valu_insts_per_launch")
         if vi and agg_ms > 0 and not fused:
             # Informational second roofline of the aggregation launch: its stored instruction count (SQ_INSTS_VALU of the committed PMC pass) x 4 cycles
-            # per wave64 instruction over 1024 SIMDs, against this run's launch time.  `frac` uses the chip's 2.4 GHz maximum clock; under this load
-            # the chip holds ~2.0 GHz, at which the same figure is `frac_at_held_clock`.  What binds the launch is the rate at which the memory system
+            # per wave64 instruction over 1024 SIMDs, against this run's launch time.  `frac` uses the chip's 2.4 GHz maximum clock (the run does not
+            # measure the clock it held; the PMC passes under profiles/ put it near 2.0 GHz under this load).  What binds the launch is the rate at which the memory system
             # takes its slab writes (profiles/r03_min3.txt: without the stores the launch is 20 % shorter and VALU-bound; with them 11 % fewer
             # instructions change nothing): the VALU floor sits 15-20 % under the write-bound time.
             issue = vi * 4.0 / 1024.0 / (agg_ms * 1e-3)
             out["roofline_valu_issue"] = {"bound": "valu-issue (informational: the floor under the write-bound launch)", "kernel": "aggregate_kernel", "valu_insts_per_launch": vi,
                                           "source": "profiles/traffic.json (stored SQ_INSTS_VALU of this configuration)",
-                                          "achieved_GHz_equivalent": round(issue / 1e9, 3), "peak_GHz": 2.4, "frac": round(issue / 2.4e9, 4),
-                                          "frac_at_held_clock": round(issue / 1.97e9, 4)}
+                                          "achieved_GHz_equivalent": round(issue / 1e9, 3), "peak_GHz": 2.4, "frac": round(issue / 2.4e9, 4)}
         if wta_ms > 0 and not fused:
             # the second kernel of the path, same accounting (PD + 4 bytes per pixel), HBM-read bound
             wta_bytes = alg_bytes_wta(w, h, D, P) * fpl
@@ -528,6 +550,9 @@ def run(args, world, rank, dev_index):
         if pcie:
             out["pcie_inclusive"] = pcie
             out["value_pcie_inclusive"] = pcie["pairs_per_s"]   # the same step with the pair uploaded and disparity + planes downloaded
+        if bgr:
+            out["bgr_input"] = bgr
+            out["value_bgr_input"] = bgr["pairs_per_s"]   # the same step on 3-channel inputs, what disparity.cu:66-67 is handed
         if seq:
             out["sequence_mode"] = seq
         if latency:

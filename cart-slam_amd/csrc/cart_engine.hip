@@ -195,10 +195,7 @@ void build_agg_args(cart_engine *e, AggArgs &a, unsigned keep) {
     // start first; slab index `path` keeps the oracle's order {down, up, right, left, diagonals}.
     struct D { int dx, dy, path; };
     static const D order8[8] = {{1, 0, 2}, {-1, 0, 3}, {0, 1, 0}, {0, -1, 1}, {1, 1, 4}, {-1, 1, 5}, {-1, -1, 6}, {1, -1, 7}};
-    unsigned mask = keep;
-#ifdef CART_EXPERIMENTS   // timing experiments only (results are wrong when directions are dropped); never in a product build
-    if (const char *m = std::getenv("CART_DEBUG_DIRMASK")) mask &= (unsigned)std::strtoul(m, nullptr, 0);
-#endif
+    const unsigned mask = keep;
     int blk = 0, nd = 0;
     const int lpb = agg_lines_per_block(g.D);
     for (int i = 0; i < g.P; ++i) {

@@ -215,11 +215,10 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 // half is a cost below 0x7C00 (no inf / NaN pattern; non-negative, so IEEE order = unsigned order) -- the recurrence's operands are
 // <= 255 + P2 < 1024, i.e. f16 denormals, which the wave's mode register must preserve (keep_f16_denormals below).  Issue cost as
 // v_pk_min_u16 (profiles/tools/valu_rate.hip), so each use saves one of ~100 instructions of the VALU-bound step.
-#ifndef CART_MIN3
-#define CART_MIN3 1
-#endif
+// (A/B against two v_pk_min_u16: profiles/r03_min3.txt.)  The instruction exists on gfx950 only -- the one target this file is written
+// for; the host pass of the compiler and any other --offload-arch get the two-instruction form.
 __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
-#if CART_MIN3
+#if defined(__gfx950__)
     uint32_t r;
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
@@ -227,13 +226,10 @@ __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) 
     return pk_min(pk_min(a, b), c);
 #endif
 }
-// MODE.FP_DENORM[3:2] (f16 / f64) = 3: denormals in and out.  It is the code object's default; set explicitly because pk_min3's
-// correctness hangs on it.  hwreg(HW_REG_MODE = 1, offset 6, width 2)
-__device__ __forceinline__ void keep_f16_denormals() {
-#if CART_MIN3
-    __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
-#endif
-}
+// MODE.FP_DENORM[3:2] (f16 / f64) = 3: denormals in and out.  That is the code object's default mode, and the default is what pk_min3
+// relies on (the asm above carries no dependency on this s_setreg, so the compiler may order the two freely; every kernel that uses
+// pk_min3 still states the mode once at its entry, so that a changed default cannot go unnoticed).  hwreg(HW_REG_MODE = 1, offset 6, width 2)
+__device__ __forceinline__ void keep_f16_denormals() { __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
 }
@@ -357,15 +353,10 @@ __device__ __forceinline__ void agg_step(uint32_t (&a)[8], uint32_t &mm, const u
         uint4 o;
         o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
         o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
-#if defined(CART_EXPERIMENTS) && defined(CART_ABLATE_STORE)  // timing experiment only: keep the bytes live, skip the slab store
-        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
-        (void)po;
-#else
         // write-once streaming data: non-temporal so the slabs do not evict the census planes from L2
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         const v4u q = {o.x, o.y, o.z, o.w};
         __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);
-#endif
     } else {
         (void)po;  // the fused WTA consumes the new costs from the registers
     }
@@ -470,25 +461,10 @@ __device__ __forceinline__ void hscan_sliding(uint32_t (&st)[8], uint32_t &mm, c
     for (int gi = 1; gi < groups; ++gi) group();
 }
 
-// prefetch depth of the vertical / diagonal scans in steps (see the note at the loop)
-#ifndef CART_VDEPTH4
-#define CART_VDEPTH4 4
-#endif
-#ifndef CART_VDEPTH8
-#define CART_VDEPTH8 2
-#endif
-#ifndef CART_VDEPTH16
-#define CART_VDEPTH16 2
-#endif
-template <int LPP> constexpr int v_depth() { return LPP == 4 ? CART_VDEPTH4 : LPP == 8 ? CART_VDEPTH8 : CART_VDEPTH16; }
+// prefetch depth of the vertical / diagonal scans in steps (see the note at the loop): 4 at D = 64 (-10 %), 2 elsewhere (flat)
+template <int LPP> constexpr int v_depth() { return LPP == 4 ? 4 : 2; }
 
-#ifndef CART_AGG_WAVES
-#define CART_AGG_WAVES 4
-#endif
-#ifndef CART_XCD_REMAP
-#define CART_XCD_REMAP 1   // 0: experiment builds only (A/B of the XCD-aware grid decode)
-#endif
-constexpr int kAggWaves = CART_AGG_WAVES;   // waves per workgroup: nothing in the kernel is shared between waves
+constexpr int kAggWaves = 4;   // waves per workgroup: nothing in the kernel is shared between waves (1-2: 1.85 instead of 1.58 ms at the headline; 8: slower but at D=64)
 template <int LPP>
 __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
     using WN = Win<LPP>;
@@ -496,9 +472,6 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     constexpr int LINES_PER_BLOCK = kAggWaves * P;
     __shared__ uint32_t s_win[kAggWaves][2][WN::BUF];
     const Geometry &g = a.g;
-#if defined(CART_EXPERIMENTS) && defined(CART_ALLPRIO)
-    __builtin_amdgcn_s_setprio(CART_ALLPRIO);
-#endif
     // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
     // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
     // XCD placement (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its
@@ -542,10 +515,7 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     if (dy == 0) {
         // ---- horizontal scans: the wave's pixels sit on P different rows, nothing to share; per-lane loads.
         // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
-#ifndef CART_HPRIO
-#define CART_HPRIO 3
-#endif
-        __builtin_amdgcn_s_setprio(CART_HPRIO);
+        __builtin_amdgcn_s_setprio(3);
         if (line >= nlines) return;
         const int y0r = a.dirs[di].jmin + line0;          // row of the wave's first line (uniform)
         const int x = dx > 0 ? 0 : g.w - 1, t1 = g.w;
@@ -672,33 +642,22 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
         uint32_t xr[16];
         int t = tm0;
         // sub-step J of a K-step trip: buffer J&1 holds the window of step t+J, fs[J] its left feature, set J is free
-#if !defined(CART_EXPERIMENTS) || !defined(CART_AGG_ABLATE)
-#undef CART_AGG_ABLATE
-#define CART_AGG_ABLATE 0   // -DCART_EXPERIMENTS -DCART_AGG_ABLATE=mask, timing experiments only (results are wrong): 1 no LDS window read, 2 no LDS window write, 4 no global loads in the loop
-#endif
         auto sub = [&](auto jc, auto reload) {
             constexpr int J = decltype(jc)::value;
             uint32_t *cur = (J & 1) ? buf1 : buf0, *nxt = (J & 1) ? buf0 : buf1;
             ca.fl = fs[J];
-            if constexpr (decltype(reload)::value && !(CART_AGG_ABLATE & 4)) {
+            if constexpr (decltype(reload)::value) {
 #pragma unroll
                 for (int i = 0; i < WN::NLD; ++i) gs[J][i] = ld_u32(pw + (J + K) * cstride, goff[i]);  // step t+J+K, issued before this step's store
                 fs[J] = ld_u32(pl + (J + K) * cstride, lo_l);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (CART_AGG_ABLATE & 1) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ca.r[k] = gs[J][k % WN::NLD] + (uint32_t)k * st[k & 7];
-            } else {
-                win_read<LPP>(cur, rbase, ca.r);
-            }
+            win_read<LPP>(cur, rbase, ca.r);
             agg_xor(ca, xr);
             agg_step<LPP>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, sgpr(po + J * ostride) + pin_v(lo_o));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(CART_AGG_ABLATE & 2)) {
 #pragma unroll
-                for (int i = 0; i < WN::NLD; ++i) nxt[lslot[i]] = gs[(J + 1) % K][i];   // window of step t+J+1
-            }
+            for (int i = 0; i < WN::NLD; ++i) nxt[lslot[i]] = gs[(J + 1) % K][i];   // window of step t+J+1
         };
         for (; t + K <= tm1; t += K) {
             sub(std::integral_constant<int, 0>{}, std::true_type{});
@@ -734,7 +693,7 @@ int agg_lines_per_block(int D) { return 64 * kAggWaves / (D / 16); }
 // 1242x375 D=128 P=8 aggregate 1.607-1.613 vs 1.619-1.631 ms (+0.7 % pairs/s), D=256 P=4 aggregate 1.21-1.23 vs 1.25-1.26,
 // D=64 P=4 level; at 1920x1080 (17 MB of census per frame) it costs the aggregate 7 % (7.83 vs 7.32 ms per 8 frames): off there.
 bool xcd_placement(const Geometry &g, int n_frames) {
-    return CART_XCD_REMAP && n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);
+    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);
 }
 
 // 4-wave workgroups of the aggregation launch allowed per CU at a time (0 = no cap: 7 fit).  One row per measured case
@@ -765,17 +724,11 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     // and the census planes the directions re-read stay in L2.  Smaller workgroups are slower (two waves or one: the headline's
     // launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64.
     constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
-    int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
-#ifdef CART_EXPERIMENTS
-    if (const char *e = std::getenv("CART_AGG_RESIDENT")) resident = std::atoi(e);
-#endif
+    const int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
     const int lpp = a.g.D / 16;
     const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
     // (never more than 64 KB per workgroup in all, the limit that needs no opt-in: two of those per CU are still two)
-    size_t pad = resident ? std::min<size_t>(kLdsPerCu / resident - kLdsGranule, 64 * 1024) - static_lds : 0;
-#ifdef CART_EXPERIMENTS
-    if (const char *e = std::getenv("CART_AGG_DYNLDS")) pad = std::strtoul(e, nullptr, 0);
-#endif
+    const size_t pad = resident ? std::min<size_t>(kLdsPerCu / resident - kLdsGranule, 64 * 1024) - static_lds : 0;
     switch (a.g.D) {
         case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, pad, s, a); break;
         case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, pad, s, a); break;
@@ -810,14 +763,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // polls the left neighbour's words of row t and puts them into the inbox.  Blocks take their position from a ticket
 // (atomic counter), so a block's left neighbour has always started before it: the pipeline cannot deadlock however many
 // blocks are resident.  Polls are bounded: on a timeout the block raises the status word, stops polling and drains.
-#ifndef CART_PAIR_WAVES
-#define CART_PAIR_WAVES 4
-#endif
-#if !defined(CART_EXPERIMENTS) || !defined(CART_PAIR_ABLATE)   // product builds: every experiment hook compiles to nothing
-#undef CART_PAIR_ABLATE
-#define CART_PAIR_ABLATE 0   // -DCART_EXPERIMENTS -DCART_PAIR_ABLATE=mask, timing experiments only (results are wrong): 1 no polling, 2 no row barrier, 4 no LDS shift of the diagonal state
-#endif
-constexpr int kPairWaves = CART_PAIR_WAVES;   // compute waves per block (+ 1 helper)
+constexpr int kPairWaves = 4;   // compute waves per block (+ 1 helper)
 constexpr uint32_t kPairSpinMax = 1u << 20;
 template <int LPP> constexpr int pair_cols() { return kPairWaves * (64 / LPP); }
 
@@ -889,7 +835,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
             if (has_left && lane < LPP) {
                 const unsigned long long *src = left + ((size_t)t * LPP + lane) * 5;
                 uint32_t pay[5] = {0, 0, 0, 0, 0};
-                if (!dead && !(CART_PAIR_ABLATE & 1)) {
+                if (!dead) {
                     bool ok = false;
                     for (uint32_t it = 0; it < kPairSpinMax && !ok; ++it) {
                         ok = true;
@@ -911,7 +857,7 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
                 s_shift[t & 1][8][lane] = (pay[4] & 0xffu) * 0x10001u;
             }
             dead = __builtin_amdgcn_readfirstlane(__any((int)dead));   // wave-uniform
-            if (!(CART_PAIR_ABLATE & 2)) lds_barrier();   // barrier(t): the compute waves have written the state of row t
+            lds_barrier();   // barrier(t): the compute waves have written the state of row t
             if (has_right && lane < LPP) {
                 const int src_lane = LPP + NT - LPP + lane;   // the block's last column
                 unsigned long long *dst = mine + ((size_t)t * LPP + lane) * 5;
@@ -970,23 +916,19 @@ __global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairA
         uint32_t uV[8], uD[8];
         pair_step<LPP>(stV, mmV, cost, sel_lo, sel_hi, p1p1, p2p2, uV);
         const int pb = (t + 1) & 1, cb = t & 1;   // previous row's buffer (row -1 = the zeroed one), this row's
-        if (!(CART_PAIR_ABLATE & 4)) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) stD[i] = s_shift[pb][i][tid];   // = lane tid - LPP of the previous row (inbox below lane 0)
-            mmD = s_shift[pb][8][tid];
-        }
+        for (int i = 0; i < 8; ++i) stD[i] = s_shift[pb][i][tid];   // = lane tid - LPP of the previous row (inbox below lane 0)
+        mmD = s_shift[pb][8][tid];
         pair_step<LPP>(stD, mmD, cost, sel_lo, sel_hi, p1p1, p2p2, uD);
-        if (!(CART_PAIR_ABLATE & 4)) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s_shift[cb][i][LPP + tid] = stD[i];
-            s_shift[cb][8][LPP + tid] = mmD;
-        }
+        for (int i = 0; i < 8; ++i) s_shift[cb][i][LPP + tid] = stD[i];
+        s_shift[cb][8][LPP + tid] = mmD;
         uint32_t s[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] = uV[i] + uD[i];   // halves <= 2*P2 <= 255
         const v4u q = {perm(s[1], s[0], 0x06040200u), perm(s[3], s[2], 0x06040200u), perm(s[5], s[4], 0x06040200u), perm(s[7], s[6], 0x06040200u)};
         __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)dst);
-        if (!(CART_PAIR_ABLATE & 2)) lds_barrier();
+        lds_barrier();
     };
 
     // software pipeline as in aggregate_kernel: the loads of step t+2 are issued before the store of step t
@@ -1316,10 +1258,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
 void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s, bool top2) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
-    size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
-#ifdef CART_EXPERIMENTS
-    if (const char *e = std::getenv("CART_WTA_DYNLDS")) lds += std::strtoul(e, nullptr, 0);   // residency experiments (unused LDS)
-#endif
+    const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
     WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, thr, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
     if (top2) {   // S5 variant (CART_OPT_SPEC_S5_TOP2)
         switch (g.D) {
@@ -1379,6 +1318,30 @@ void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint3
 #define CART_FUSED_WAVES_16 4
 #endif
 constexpr int fused_waves(int lpp) { return lpp >= 16 ? CART_FUSED_WAVES_16 : CART_FUSED_WAVES_LE8; }
+// ---- round-4 development knobs of the fused sweep (removed once measured) ----
+#ifndef CART_F_SETS8
+#define CART_F_SETS8 2      // slab rows in flight per wave, 8-path sweeps
+#endif
+#ifndef CART_F_SETS4
+#define CART_F_SETS4 2      // ... 4-path sweeps
+#endif
+#ifndef CART_F_MINW8
+#define CART_F_MINW8 3      // launch bound: waves per SIMD the register allocation must allow, 8-path sweeps
+#endif
+#ifndef CART_F_MINW4
+#define CART_F_MINW4 3
+#endif
+#ifndef CART_F_RVSPEC
+#define CART_F_RVSPEC 0     // padded right-view rows: the pad carry of the 16 slots from compile-time lane masks, one code version per wave class
+#endif
+#ifndef CART_F_PKMAD
+#define CART_F_PKMAD 0      // argmin keys by v_pk_mad_u16
+#endif
+#ifndef CART_F_RVLAST
+#define CART_F_RVLAST 0     // right-view LDS atomics issued after the pixel record (its LDS reads no longer queue behind them)
+#endif
+constexpr int fused_sets(int np) { return np <= 4 ? CART_F_SETS4 : CART_F_SETS8; }
+constexpr int fused_minw(int np) { return np <= 4 ? CART_F_MINW4 : CART_F_MINW8; }
 #ifndef CART_FUSED_RB
 #define CART_FUSED_RB 16
 #endif
@@ -1403,13 +1366,13 @@ template <int LPP, int NP>
 struct FusedRegs {
     uint32_t win[Win<LPP>::NLD];
     uint32_t fl;
-    uint32_t sv[2][NP - 1][4];   // two rows of slab bytes in flight (see the Little's-law note at the kernel)
+    uint32_t sv[fused_sets(NP)][NP - 1][4];   // rows of slab bytes in flight (see the Little's-law note at the kernel)
 };
 
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
 template <int LPP, int NP, int WPB_ = fused_waves(LPP)>
-__global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU); 4 for the 4-path variants (120 VGPRs, 39 KB of LDS) measured the same
+__global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU); 4 for the 4-path variants (120 VGPRs, 39 KB of LDS) measured the same
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = WPB_, NT = 64 * WPB;
@@ -1475,8 +1438,9 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
         for (int i = 0; i < WN::NLD; ++i) r.win[i] = ld_u32(pw, goff[i]);
         r.fl = ld_u32(pl0 + (ptrdiff_t)y * g.cpitch, lo_l);
     };
+    constexpr int SETS = fused_sets(NP);
     auto load_slab_row = [&](int y, auto set_c) {
-        constexpr int SET = decltype(set_c)::value;
+        constexpr int SET = decltype(set_c)::value % SETS;
         const uint8_t *ps = ps0 + (ptrdiff_t)((CART_FUSED_ABLATE & 32) ? (y & 1) : y) * row_bytes;  // 32: all rows from two L2-resident ones
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1517,7 +1481,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
     };
 
     auto wta = [&](const uint32_t (&sp)[8], int lr, int y, auto set_c) {   // sp: path costs of row y; lr: LDS output row
-        constexpr int SET = decltype(set_c)::value;
+        constexpr int SET = decltype(set_c)::value % SETS;
         // ---- S in natural adjacent pairs: sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q])
         uint32_t sm[8];
 #pragma unroll
@@ -1533,7 +1497,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
                 sm[4 + q] += perm(0u, r.sv[SET][k][q], 0x0c030c01u);
             }
         }
-        load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
+        load_slab_row(max(y - SETS, 0), set_c);   // this slab set is free again: prefetch row y-SETS into it
         uint16_t *tile = &s_tile[0][0];   // single buffer: every wave only touches the rows of its own pixels
         v4u *dst = reinterpret_cast<v4u *>(tile + xl * DP + d0);
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
@@ -1542,8 +1506,16 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
         uint32_t key[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+#if CART_F_PKMAD
+            // key = S * 16 + local index in ONE packed multiply-add (VOP3P takes no literal: the index pair sits in an SGPR; the inline
+            // constant 16 serves both halves through op_sel_hi)
+            uint32_t idx = (uint32_t)(2 * k) | ((uint32_t)(2 * k + 1) << 16);
+            asm volatile("" : "+s"(idx));
+            asm("v_pk_mad_u16 %0, %1, 16, %2 op_sel_hi:[1,0,1]" : "=v"(key[k]) : "v"(sm[k]), "s"(idx));
+#else
             const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
             key[k] = __builtin_bit_cast(uint32_t, kk);
+#endif
         }
         uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
         m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
@@ -1556,18 +1528,60 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
         for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
         const uint32_t tot = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
         // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d
-        if (valid && !(CART_FUSED_ABLATE & (2 | 64))) {
-            uint32_t *rrow = &s_rmin[lr][0];
-            const int base = xl + D - 1 - d0, s0 = RVPAD ? rv_slot(base) : base;
-            int b4 = base & 15;
-            if constexpr (RVPAD) asm volatile("" : "+v"(b4));   // recompute the 16 slots every row: hoisted, they spill
+        auto right_view = [&]() {
+            if (valid && !(CART_FUSED_ABLATE & (2 | 64))) {
+                uint32_t *rrow = &s_rmin[lr][0];
+#if CART_F_RVSPEC
+                if constexpr (RVPAD) {
+                    // Slot of entry base - j = s0 - j - [j > b4] with b4 = (xl - 1) & 15 and xl = 4 wid + pg (P = 4 pixels per wave, 16 lanes each):
+                    // the carry depends on the lane only through pg = lane >> 4, and on the wave only through wid & 3.  One code version per wave
+                    // class, in which every carry is a COMPILE-TIME lane mask: all lanes (slot row B = s0 - 1 - j), none (row A = s0 - j), or one
+                    // of six partial masks (one v_cndmask).  <= 3 selects per row instead of 45 compare / select / shift instructions.
+                    static_assert(P == 4 && LPP == 16, "lane masks below assume four 16-lane pixels per wave");
+                    const int s0 = rv_slot(xl + D - 1 - d0);
+                    uint32_t *pa = rrow + s0, *pb = rrow + s0 - 1;
+                    auto emit = [&](auto wc) {
+                        constexpr int W4 = decltype(wc)::value;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
-                atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da) : s0 - da), (sm[q] << 16) | (uint32_t)(d0 + da));
-                atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da + 1) : s0 - da - 1), (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+                        for (int j = 0; j < 16; ++j) {
+                            unsigned long long mask = 0;   // lanes whose slot carries the pad: j > b4(pg)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (j > ((4 * W4 + q - 1) & 15)) mask |= 0xffffull << (16 * q);
+                            uint32_t *pj;
+                            if (mask == 0) pj = pa;
+                            else if (mask == ~0ull) pj = pb;
+                            else {
+                                uint32_t lo = (uint32_t)(uintptr_t)pa, hi = (uint32_t)(uintptr_t)pb, sel;   // LDS addresses are 32-bit
+                                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(lo), "v"(hi), "s"(mask));
+                                pj = (uint32_t *)(uintptr_t)sel;
+                            }
+                            const int q = j < 8 ? j / 2 : 4 + (j - 8) / 2;   // sm[q] holds local disparities (2q', 2q'+1), low / high half
+                            const uint32_t keyv = (j & 1) ? ((sm[q] & 0xffff0000u) | (uint32_t)(d0 + j)) : ((sm[q] << 16) | (uint32_t)(d0 + j));
+                            atomicMin(pj - j, keyv);
+                        }
+                    };
+                    switch (wid & 3) {   // wave-uniform
+                        case 0: emit(std::integral_constant<int, 0>{}); break;
+                        case 1: emit(std::integral_constant<int, 1>{}); break;
+                        case 2: emit(std::integral_constant<int, 2>{}); break;
+                        default: emit(std::integral_constant<int, 3>{}); break;
+                    }
+                    return;
+                }
+#endif
+                const int base = xl + D - 1 - d0, s0 = RVPAD ? rv_slot(base) : base;
+                int b4 = base & 15;
+                if constexpr (RVPAD) asm volatile("" : "+v"(b4));   // recompute the 16 slots every row: hoisted, they spill
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
+                    atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da) : s0 - da), (sm[q] << 16) | (uint32_t)(d0 + da));
+                    atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da + 1) : s0 - da - 1), (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+                }
             }
-        }
+        };
+        if (!CART_F_RVLAST) right_view();
         // No block barrier: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave (LDS
         // operations of one wave execute in order); the block-wide arrays (s_rmin, s_rec) are only read in the burst.
         // The pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
@@ -1581,6 +1595,7 @@ __global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) { 
             const uint32_t unique = (int)tot == tot_nbr ? 1u : 0u;
             s_rec[lr][xl] = make_uint2((uint32_t)bd | (unique << 8) | ((uint32_t)bc << 9), (uint32_t)l | ((uint32_t)rr << 16));
         }
+        if (CART_F_RVLAST) right_view();
     };
 
     // one pipelined iteration: WTA of sweep step r (image row h-1-r) + path costs of step r+1

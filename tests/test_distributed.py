@@ -70,12 +70,12 @@ def test_shard_ids_partition():
     assert ids == list(range(first, first + world * n_local))
 
 
-def _worker(rank, world, port, n_local, steps, q):
+def _worker(rank, world, port, n_local, steps, ui, ri, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         hists = make_hists(world * n_local * steps)
-        sch = PlaneParameterSchedule("histogram_peak", update_interval=7, reset_interval=2)
+        sch = PlaneParameterSchedule("histogram_peak", update_interval=ui, reset_interval=ri)
         mine = []
         next_id = 1
         for s in range(steps):
@@ -92,19 +92,22 @@ def _worker(rank, world, port, n_local, steps, q):
         dist.destroy_process_group()
 
 
-def test_world_size_2_gloo_equals_single_process():
-    world, n_local, steps = 2, 5, 4
+@pytest.mark.parametrize("world,n_local,steps,ui,ri", [(2, 5, 4, 7, 2), (8, 8, 2, 30, 10)])
+def test_world_size_2_gloo_equals_single_process(world, n_local, steps, ui, ri):
+    """Two ranks, and BASELINE configs[4]'s own partition: EIGHT ranks x 8 frames = a 64-frame step (two of them: ids 1..128 with the
+    reference's update interval 30, refreshes at 1 / 31 / 61 / 91 / 121) -- every rank gets, for its frames, the parameters one
+    process gets feeding the frames in id order."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, steps, ui, ri, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=60) for _ in range(world)]
+    results = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    exp = sequential_reference(make_hists(world * n_local * steps), 7, 2)
+    exp = sequential_reference(make_hists(world * n_local * steps), ui, ri)
     seen = {}
     for _, mine in results:
         for fid, params in mine:
@@ -218,13 +221,15 @@ def _pipeliner_worker(rank, world, port, lengths, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lengths", [(2, (8, 7, 1, 6)), (4, (13, 3, 16, 5))])
+@pytest.mark.parametrize("world,lengths", [(2, (8, 7, 1, 6)), (4, (13, 3, 16, 5)), (8, (64, 63, 65, 7))])
 def test_pipelined_sequences_equal_one_at_a_time(world, lengths):
-    """SequencePipeliner over gloo, two and four ranks: four back-to-back sequences (lengths that divide, that leave a
+    """SequencePipeliner over gloo, two, four and EIGHT ranks (the driver's SCALE shape: configs[4]'s 64 frames dealt 8 per rank,
+    then 63 and 65 -- a length that does not divide is NOT rejected: frame k -> rank k mod N, the first n mod N ranks hold one frame
+    more, short shares travel padded -- and 7, which leaves rank 7 without a frame): four back-to-back sequences (lengths that divide, that leave a
     remainder, and that are shorter than the world, so that some ranks hold no frame at all) give the same gathered outputs
     whether each is waited for before the next is submitted or all are submitted first -- the order in which scatter(i+1) and
     gather(i) are posted is the same on every rank, so no collective can pair with the wrong one."""
-    results, _ = _spawn(_pipeliner_worker, world, (lengths,))
+    results, _ = _spawn(_pipeliner_worker, world, (lengths,), timeout=180)
     assert sorted(r for r, _ in results) == list(range(world)) and all(ok for _, ok in results)
 
 

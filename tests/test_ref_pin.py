@@ -1,8 +1,12 @@
 """Oracle and engine against outputs of the reference's own SGM dependency (cv::cuda::StereoSGM), when someone with
 OpenCV-CUDA has produced them with tools/ref_pin (tests/golden/ref/ref_disparity_<case>.bin).  The development container
-has no OpenCV, so the files do not exist yet and these tests are skipped: parity stays "unpinned" until they do."""
+has no OpenCV, so the files do not exist yet and the comparisons are skipped: parity stays "unpinned" until they do.
+What is NOT skipped: the kit itself, end to end against a FAKE reference (an oracle run with two spec variants flipped,
+written in ref_pin.cpp's file format) -- so that whoever has OpenCV-CUDA pins the oracle and does not debug the kit."""
 import glob
+import importlib.util
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -11,7 +15,19 @@ import oracle_lib as O
 from cartslam import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF = sorted(glob.glob(os.path.join(HERE, "golden", "ref", "ref_disparity_*.bin")))
+ROOT = os.path.dirname(HERE)
+REF_DIR = os.environ.get("CART_REF_PIN_DIR", os.path.join(HERE, "golden", "ref"))   # where ref_pin wrote its files
+
+
+def ref_files(ref_dir=None):
+    return sorted(glob.glob(os.path.join(ref_dir or REF_DIR, "ref_disparity_*.bin")))
+
+
+def case_name(path):
+    return os.path.basename(path)[len("ref_disparity_"):-4]
+
+
+REF = ref_files()
 
 
 def case_inputs(name):
@@ -27,34 +43,44 @@ def case_inputs(name):
     return l, r, 4, D, P
 
 
+VARIANT_BITS = "bit 1 = S8 `d <= 0` invalid, 2 = S7 replicated-border medians, 4 = S5 top-2 uniqueness"
+
+
 def explain(got, ref, l, r, md, D, P):
     """Which open upstream question (tools/ref_pin/README.md) would account for the difference."""
     by_variant = {v: int((O.disparity_module(l, r, D, P, md, radius=-1, variants=v) != ref).sum()) for v in range(1, 8)}
     best = min(by_variant, key=by_variant.get)
-    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; by variant set (bit 1 = S8 `d <= 0` invalid, "
-            f"2 = S7 replicated-border medians, 4 = S5 top-2 uniqueness): {by_variant}; the closest is {best} with {by_variant[best]} "
-            "differing pixels (tools/ref_pin/README.md: all three are switchable defaults)")
+    return (f"{int((got != ref).sum())} of {ref.size} pixels differ from the reference; by variant set ({VARIANT_BITS}): {by_variant}; "
+            f"the closest is {best} with {by_variant[best]} differing pixels (tools/ref_pin/README.md: all three are switchable defaults)")
 
 
-@pytest.mark.skipif(not REF, reason="no reference outputs yet: run tools/ref_pin on a machine with OpenCV-CUDA")
-@pytest.mark.parametrize("path", REF, ids=[os.path.basename(p)[len("ref_disparity_"):-4] for p in REF])
-def test_oracle_matches_reference_sgm(path):
-    name = os.path.basename(path)[len("ref_disparity_"):-4]
-    l, r, md, D, P = case_inputs(name)
-    ref = np.fromfile(path, np.int16).reshape(l.shape[:2])
+def load_ref(path):
+    """One ref_pin output: raw CV_16SC1, rows tight, the size of the case's input images."""
+    l, r, md, D, P = case_inputs(case_name(path))
+    raw = np.fromfile(path, np.int16)
+    assert raw.size == l.shape[0] * l.shape[1], f"{path}: {raw.size} values for a {l.shape[1]}x{l.shape[0]} case"
+    return raw.reshape(l.shape[:2]), (l, r, md, D, P)
+
+
+def check_oracle_against(path):
+    ref, (l, r, md, D, P) = load_ref(path)
     got = O.disparity_module(l, r, D, P, md, radius=-1)
     assert (got == ref).all(), explain(got, ref, l, r, md, D, P)
 
 
+@pytest.mark.skipif(not REF, reason="no reference outputs yet: run tools/ref_pin on a machine with OpenCV-CUDA")
+@pytest.mark.parametrize("path", REF, ids=[case_name(p) for p in REF])
+def test_oracle_matches_reference_sgm(path):
+    check_oracle_against(path)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not REF, reason="no reference outputs yet: run tools/ref_pin on a machine with OpenCV-CUDA")
-@pytest.mark.parametrize("path", REF, ids=[os.path.basename(p)[len("ref_disparity_"):-4] for p in REF])
+@pytest.mark.parametrize("path", REF, ids=[case_name(p) for p in REF])
 def test_engine_matches_reference_sgm(path):
     import torch
     from cartslam import Engine
-    name = os.path.basename(path)[len("ref_disparity_"):-4]
-    l, r, md, D, P = case_inputs(name)
-    ref = np.fromfile(path, np.int16).reshape(l.shape[:2])
+    ref, (l, r, md, D, P) = load_ref(path)
     eng = Engine(l.shape[1], l.shape[0], num_disparities=D, paths=P, min_disparity=md, smoothing_radius=-1, max_inflight=1)
     got = eng.compute_disparity(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()).cpu().numpy()
     eng.close()
@@ -66,3 +92,84 @@ def test_case_names_resolve():
     for name in ("road_160x96_d64_p4_gray", "full_1242x375_d128_p8_pole"):
         l, r, md, D, P = case_inputs(name)
         assert l.shape == r.shape and D in (64, 128, 256) and P in (4, 8) and md >= 0
+
+
+# ---------------------------------------------------------------- the kit against a fake reference (runs everywhere)
+def _export_module():
+    spec = importlib.util.spec_from_file_location("ref_pin_export_inputs", os.path.join(ROOT, "tools", "ref_pin", "export_inputs.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+FAKE_CASES = ["road_160x96_d64_p4_gray", "road_200x120_d128_p8_bgr"]   # one gray, one BGR (cvtColor on the reference's side)
+
+
+def _write_fake_reference(out_dir, variants):
+    """What ref_pin.cpp leaves behind, produced by the oracle with `variants` flipped: ref_disparity_<case>.bin + OPENCV_VERSION.txt."""
+    os.makedirs(out_dir, exist_ok=True)
+    for name in FAKE_CASES:
+        l, r, md, D, P = case_inputs(name)
+        O.disparity_module(l, r, D, P, md, radius=-1, variants=variants).astype(np.int16).tofile(os.path.join(out_dir, f"ref_disparity_{name}.bin"))
+    open(os.path.join(out_dir, "OPENCV_VERSION.txt"), "w").write("fake\n")
+
+
+def test_kit_names_the_variant_of_a_fake_reference(tmp_path):
+    """A reference that differs from the oracle's defaults in S8 and S5 (variant set 5): the loader finds the files, the default spec
+    fails with the documented message, and that message names set 5 with 0 differing pixels -- the line a maintainer acts on."""
+    d = str(tmp_path / "ref")
+    _write_fake_reference(d, variants=5)
+    files = ref_files(d)
+    assert [case_name(p) for p in files] == sorted(FAKE_CASES)
+    for p in files:
+        with pytest.raises(AssertionError) as ei:
+            check_oracle_against(p)
+        msg = str(ei.value)
+        assert "pixels differ from the reference" in msg and VARIANT_BITS in msg
+        assert "the closest is 5 with 0 differing pixels" in msg, msg
+        # and the answer is unambiguous: no other variant set reproduces the file
+        ref, (l, r, md, D, P) = load_ref(p)
+        for v in (1, 2, 3, 4, 6, 7):
+            assert (O.disparity_module(l, r, D, P, md, radius=-1, variants=v) != ref).any(), v
+
+
+def test_kit_passes_on_a_reference_that_agrees(tmp_path):
+    d = str(tmp_path / "ref")
+    _write_fake_reference(d, variants=0)
+    for p in ref_files(d):
+        check_oracle_against(p)
+    # a file of the wrong size (another image size, a truncated copy) is reported as such, not as a parity failure
+    bad = os.path.join(d, "ref_disparity_road_160x96_d64_p4_gray.bin")
+    open(bad, "ab").write(b"\0\0")
+    with pytest.raises(AssertionError, match="values for a 160x96 case"):
+        check_oracle_against(bad)
+
+
+def test_exported_pngs_decode_to_the_golden_inputs(tmp_path):
+    """export_inputs.py's PNGs, read back by the repo's own PNG reader (host/src/png.cpp = cv::imread's result: BGR, gray
+    replicated), are the golden arrays bit for bit -- gray and BGR -- and cases.txt lists what ref_pin.cpp expects."""
+    exe = os.path.join(ROOT, "cart-slam_amd", "build", "runtime_test")
+    if not os.path.exists(exe):
+        pytest.skip("host tools not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = str(tmp_path / "inputs")
+    cases = _export_module().export(out, full_size=False)
+    listed = [ln.split() for ln in open(os.path.join(out, "cases.txt")).read().splitlines()]
+    assert [(n, int(a), int(b), int(c)) for n, a, b, c in listed] == cases and len(cases) >= 4
+    seen_gray = seen_bgr = False
+    for name, md, D, P in cases:
+        l, r, md2, D2, P2 = case_inputs(name)
+        assert (md, D, P) == (md2, D2, P2)
+        for side, img in (("left", l), ("right", r)):
+            res = subprocess.run([exe, "--png", os.path.join(out, f"{name}_{side}.png")], capture_output=True, timeout=60)
+            assert res.returncode == 0, res.stdout[:200]
+            head, _, body = res.stdout.partition(b"\n")
+            w, h, c = (int(v) for v in head.split())
+            got = np.frombuffer(body, np.uint8).reshape(h, w, c)
+            assert (w, h, c) == (img.shape[1], img.shape[0], 3)
+            if img.ndim == 2:   # gray PNG: cv::imread(IMREAD_UNCHANGED) in ref_pin.cpp keeps one channel; the reader here replicates it
+                assert (got == img[:, :, None]).all(), (name, side)
+                seen_gray = True
+            else:               # colour PNG stores RGB, cv::imread hands back BGR = the golden array's order
+                assert (got == img).all(), (name, side)
+                seen_bgr = True
+    assert seen_gray and seen_bgr

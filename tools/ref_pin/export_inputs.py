@@ -27,9 +27,10 @@ def write_png(path, img):
                 + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def main():
+def export(out, full_size=True):
+    """Writes <case>_left.png / <case>_right.png + cases.txt into `out`; -> the cases [(name, min_disp, D, P)].
+    full_size=False: the golden fixtures only (what tests/test_ref_pin.py round-trips through the repo's PNG reader)."""
     from cartslam import synth
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "inputs")
     os.makedirs(out, exist_ok=True)
     cases = []
     for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "road_*.npz"))):
@@ -37,19 +38,21 @@ def main():
         name = os.path.basename(f)[:-4]
         write_png(os.path.join(out, name + "_left.png"), z["left"]); write_png(os.path.join(out, name + "_right.png"), z["right"])
         cases.append((name, int(z["min_disp"]), int(z["D"]), int(z["P"])))
-    for scene in synth.SCENES:   # the headline configuration on every scene variant, and the reference's defaults on the road
+    for scene in (synth.SCENES if full_size else ()):   # the headline configuration on every scene variant, and the reference's defaults on the road
         l, r, _ = synth.make_pair(1242, 375, 128, 4, scene=scene)
         name = f"full_1242x375_d128_p8_{scene}"
         write_png(os.path.join(out, name + "_left.png"), l); write_png(os.path.join(out, name + "_right.png"), r)
         cases.append((name, 4, 128, 8))
-    l, r, _ = synth.make_pair(1242, 375, 256, 4)
-    write_png(os.path.join(out, "full_1242x375_d256_p4_road_left.png"), l); write_png(os.path.join(out, "full_1242x375_d256_p4_road_right.png"), r)
-    cases.append(("full_1242x375_d256_p4_road", 4, 256, 4))
+    if full_size:
+        l, r, _ = synth.make_pair(1242, 375, 256, 4)
+        write_png(os.path.join(out, "full_1242x375_d256_p4_road_left.png"), l); write_png(os.path.join(out, "full_1242x375_d256_p4_road_right.png"), r)
+        cases.append(("full_1242x375_d256_p4_road", 4, 256, 4))
     with open(os.path.join(out, "cases.txt"), "w") as f:
         for c in cases:
             f.write("%s %d %d %d\n" % c)
-    print(f"{len(cases)} cases written to {out}")
+    return cases
 
 
 if __name__ == "__main__":
-    main()
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "inputs")
+    print(f"{len(export(out_dir))} cases written to {out_dir}")
