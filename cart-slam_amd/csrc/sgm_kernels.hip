@@ -487,11 +487,11 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     const int nblk = (a.dirs[di].nlines + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK;
     const int rb = bid - a.dirs[di].blk0 * nfr;
     const int frame = frame0 + fstep * (rb / nblk);
-    const int b = rb - (rb / nblk) * nblk + a.dirs[di].blk0;
+    const int bl = rb - (rb / nblk) * nblk;   // block inside the frame's share of this direction
     const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
     const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP;  // lane inside the pixel's lane group, pixel group inside the wave
-    const int line0 = (b - a.dirs[di].blk0) * LINES_PER_BLOCK + wid * P;  // wave-uniform
+    const int line0 = bl * LINES_PER_BLOCK + wid * P;  // wave-uniform
     const int line = line0 + pg;
     const int nlines = a.dirs[di].nlines;
     if (line0 >= nlines) return;  // whole wave idle
@@ -1023,8 +1023,6 @@ __host__ __device__ constexpr uint32_t rv_key32(uint32_t key16, int e, int cols,
     const int sh = cols == 32 ? 5 : 4, base = D - 1 - e;
     return ((key16 >> sh) << 16) | (uint32_t)(base + (((int)(key16 & (uint32_t)(cols - 1)) - base) & (cols - 1)));
 }
-// slot of entry base - j for j in [0, 15], from s0 = rv_slot(base) and b4 = base & 15 (base >= 15)
-__device__ __forceinline__ int rv_slot_below(int s0, int b4, int j) { return s0 - j - (j > b4 ? 1 : 0); }
 
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -1303,52 +1301,15 @@ void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint3
 // The row loop has no block barrier (the LDS sum tile is only read by the wave that wrote it); left disparities and
 // right-view minima are buffered in LDS for 16 rows and written out in one burst between two barriers, so the row
 // loop itself holds loads only and the prefetches stay in flight while a row is processed.
-#if !defined(CART_EXPERIMENTS) || !defined(CART_FUSED_ABLATE)   // product builds: every experiment hook compiles to nothing
-#undef CART_FUSED_ABLATE
-#define CART_FUSED_ABLATE 0   // -DCART_EXPERIMENTS -DCART_FUSED_ABLATE=mask, timing experiments only: 1 no global flush, 2 no LDS right-view atomics, 4 no slab loads, 8 no partial stores, 16 no wta_l store, 32 slab rows from L2, 64 no LDS right view, 128 no recurrence, 256 no WTA
-#endif
 // Waves per block of the fused sweep.  The sweep has frames*W/(64/LPP) waves in total (2484 at 16 x 1242, D=128: 2.4 per
 // SIMD), so small blocks spread them evenly over the CUs: with 4-wave blocks a quarter of the CUs carried 3 blocks, the
 // rest 2, and the launch took the time of 3.  D=256 keeps 4 waves: its blocks would otherwise be 8 columns wide and the
 // right-view partial rows (columns + D - 1 entries per block and row) would grow to 17 % of the slab traffic.
-#ifndef CART_FUSED_WAVES_LE8
-#define CART_FUSED_WAVES_LE8 2
-#endif
-#ifndef CART_FUSED_WAVES_16
-#define CART_FUSED_WAVES_16 4
-#endif
-constexpr int fused_waves(int lpp) { return lpp >= 16 ? CART_FUSED_WAVES_16 : CART_FUSED_WAVES_LE8; }
-// ---- round-4 development knobs of the fused sweep (removed once measured) ----
-#ifndef CART_F_SETS8
-#define CART_F_SETS8 2      // slab rows in flight per wave, 8-path sweeps
-#endif
-#ifndef CART_F_SETS4
-#define CART_F_SETS4 2      // ... 4-path sweeps
-#endif
-#ifndef CART_F_MINW8
-#define CART_F_MINW8 3      // launch bound: waves per SIMD the register allocation must allow, 8-path sweeps
-#endif
-#ifndef CART_F_MINW4
-#define CART_F_MINW4 3
-#endif
-#ifndef CART_F_RVSPEC
-#define CART_F_RVSPEC 0     // padded right-view rows: the pad carry of the 16 slots from compile-time lane masks, one code version per wave class
-#endif
-#ifndef CART_F_PKMAD
-#define CART_F_PKMAD 0      // argmin keys by v_pk_mad_u16
-#endif
-#ifndef CART_F_RVLAST
-#define CART_F_RVLAST 0     // right-view LDS atomics issued after the pixel record (its LDS reads no longer queue behind them)
-#endif
-constexpr int fused_sets(int np) { return np <= 4 ? CART_F_SETS4 : CART_F_SETS8; }
-constexpr int fused_minw(int np) { return np <= 4 ? CART_F_MINW4 : CART_F_MINW8; }
-#ifndef CART_FUSED_RB
-#define CART_FUSED_RB 16
-#endif
-constexpr int kFusedRB = CART_FUSED_RB;   // rows buffered in LDS between two bursts of the fused sweep
+constexpr int fused_waves(int lpp) { return lpp >= 16 ? 4 : 2; }
+constexpr int kFusedRB = 16;   // rows buffered in LDS between two bursts of the fused sweep (8 and 32 measured level / slower)
 // ... except on wide images at D = 256, where blocks of 8 waves (32 columns) give ~one block per CU and halve the partial
 // right-view rows again: 1920x1080, 4 frames: 2.65 instead of 3.08 ms per launch (at 1242 wide 8 waves lose 10 %)
-inline int fused_waves_for(const Geometry &g) { return g.D >= 256 && g.w >= 1600 ? 2 * CART_FUSED_WAVES_16 : fused_waves(g.D / 16); }
+inline int fused_waves_for(const Geometry &g) { return g.D >= 256 && g.w >= 1600 ? 2 * fused_waves(16) : fused_waves(g.D / 16); }
 
 
 struct FusedArgs {
@@ -1366,13 +1327,13 @@ template <int LPP, int NP>
 struct FusedRegs {
     uint32_t win[Win<LPP>::NLD];
     uint32_t fl;
-    uint32_t sv[fused_sets(NP)][NP - 1][4];   // rows of slab bytes in flight (see the Little's-law note at the kernel)
+    uint32_t sv[2][NP - 1][4];   // two rows of slab bytes in flight (see the Little's-law note at the kernel; one row at <= 128 VGPRs measured slower, profiles/r04_fused.txt)
 };
 
 // NP = number of paths (compile time: every VMEM instruction of the row loop is unconditional, so that the compiler
 // can use exact counted vmcnt waits and the loads of row y-1 stay in flight while row y is processed)
 template <int LPP, int NP, int WPB_ = fused_waves(LPP)>
-__global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU); 4 for the 4-path variants (120 VGPRs, 39 KB of LDS) measured the same
+__global__ __launch_bounds__(64 * WPB_, 3) void wta_fused_kernel(FusedArgs a) {  // >= 3 waves per SIMD (HIP: min waves per EU); 4 for the 4-path variants (120 VGPRs, 39 KB of LDS) measured the same
     using WN = Win<LPP>;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     constexpr int WPB = WPB_, NT = 64 * WPB;
@@ -1438,17 +1399,14 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
         for (int i = 0; i < WN::NLD; ++i) r.win[i] = ld_u32(pw, goff[i]);
         r.fl = ld_u32(pl0 + (ptrdiff_t)y * g.cpitch, lo_l);
     };
-    constexpr int SETS = fused_sets(NP);
     auto load_slab_row = [&](int y, auto set_c) {
-        constexpr int SET = decltype(set_c)::value % SETS;
-        const uint8_t *ps = ps0 + (ptrdiff_t)((CART_FUSED_ABLATE & 32) ? (y & 1) : y) * row_bytes;  // 32: all rows from two L2-resident ones
+        constexpr int SET = decltype(set_c)::value;
+        const uint8_t *ps = ps0 + (ptrdiff_t)y * row_bytes;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (p == kUpPath) continue;
             const int k = p < kUpPath ? p : p - 1;  // compile-time after unrolling
-            const v4u v = (CART_FUSED_ABLATE & 4)
-                              ? v4u{0x01010101u * (uint32_t)(y & 7), 0x02020202u, 0x03030303u, 0x04040404u}
-                              : __builtin_nontemporal_load((const CART_GLOBAL v4u *)((const CART_GLOBAL char *)sgpr(ps + (ptrdiff_t)p * (ptrdiff_t)g.slab_bytes) + pin_v(lo_s)));
+            const v4u v = __builtin_nontemporal_load((const CART_GLOBAL v4u *)((const CART_GLOBAL char *)sgpr(ps + (ptrdiff_t)p * (ptrdiff_t)g.slab_bytes) + pin_v(lo_s)));
             r.sv[SET][k][0] = v.x; r.sv[SET][k][1] = v.y; r.sv[SET][k][2] = v.z; r.sv[SET][k][3] = v.w;
         }
     };
@@ -1463,7 +1421,6 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
     // instruction streams are independent, so the scheduler interleaves them and the long latency chains of one (LDS
     // round trips, DPP reductions) are filled with the other's work.
     auto agg = [&](int y) {   // census registers hold row y; they are re-loaded for row y-1 once consumed
-        if (CART_FUSED_ABLATE & 1024) return;   // timing experiment: no census loads, no window staging, no recurrence
 #pragma unroll
         for (int i = 0; i < WN::NLD; ++i) wbuf[lslot[i]] = r.win[i];
         CensusRegs c;
@@ -1472,16 +1429,11 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
         uint32_t xr[16];
         agg_xor(c, xr);
         load_census_row(max(y - 1, 0));
-        if (CART_FUSED_ABLATE & 128) {   // timing experiment: no recurrence (keeps the loads and the xor alive)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) st[i] ^= xr[i] ^ xr[8 + i];
-        } else {
-            agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
-        }
+        agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);
     };
 
     auto wta = [&](const uint32_t (&sp)[8], int lr, int y, auto set_c) {   // sp: path costs of row y; lr: LDS output row
-        constexpr int SET = decltype(set_c)::value % SETS;
+        constexpr int SET = decltype(set_c)::value;
         // ---- S in natural adjacent pairs: sm[q] = (S[d0+2q], S[d0+2q+1]), sm[4+q] = (S[d0+8+2q], S[d0+9+2q])
         uint32_t sm[8];
 #pragma unroll
@@ -1497,7 +1449,7 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
                 sm[4 + q] += perm(0u, r.sv[SET][k][q], 0x0c030c01u);
             }
         }
-        load_slab_row(max(y - SETS, 0), set_c);   // this slab set is free again: prefetch row y-SETS into it
+        load_slab_row(max(y - 2, 0), set_c);   // this slab set is free again: prefetch row y-2 into it
         uint16_t *tile = &s_tile[0][0];   // single buffer: every wave only touches the rows of its own pixels
         v4u *dst = reinterpret_cast<v4u *>(tile + xl * DP + d0);
         dst[0] = v4u{sm[0], sm[1], sm[2], sm[3]};
@@ -1506,16 +1458,9 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
         uint32_t key[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-#if CART_F_PKMAD
-            // key = S * 16 + local index in ONE packed multiply-add (VOP3P takes no literal: the index pair sits in an SGPR; the inline
-            // constant 16 serves both halves through op_sel_hi)
-            uint32_t idx = (uint32_t)(2 * k) | ((uint32_t)(2 * k + 1) << 16);
-            asm volatile("" : "+s"(idx));
-            asm("v_pk_mad_u16 %0, %1, 16, %2 op_sel_hi:[1,0,1]" : "=v"(key[k]) : "v"(sm[k]), "s"(idx));
-#else
+            // (a shift and an or per register; one v_pk_mad_u16 with the index pair in an SGPR measured level to slower, profiles/r04_fused.txt)
             const u16x2 kk = __builtin_bit_cast(u16x2, sm[k]) * (u16x2){16, 16} + (u16x2){(uint16_t)(2 * k), (uint16_t)(2 * k + 1)};
             key[k] = __builtin_bit_cast(uint32_t, kk);
-#endif
         }
         uint32_t m = pk_min(pk_min(pk_min(key[0], key[1]), pk_min(key[2], key[3])), pk_min(pk_min(key[4], key[5]), pk_min(key[6], key[7])));
         m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16)) & 0xffffu;
@@ -1527,61 +1472,60 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = pk_add(acc, pk_sub_sat(tt, sm[k]));
         const uint32_t tot = group_allsum<LPP>((acc & 0xffffu) + (acc >> 16));
-        // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d
-        auto right_view = [&]() {
-            if (valid && !(CART_FUSED_ABLATE & (2 | 64))) {
-                uint32_t *rrow = &s_rmin[lr][0];
-#if CART_F_RVSPEC
-                if constexpr (RVPAD) {
-                    // Slot of entry base - j = s0 - j - [j > b4] with b4 = (xl - 1) & 15 and xl = 4 wid + pg (P = 4 pixels per wave, 16 lanes each):
-                    // the carry depends on the lane only through pg = lane >> 4, and on the wave only through wid & 3.  One code version per wave
-                    // class, in which every carry is a COMPILE-TIME lane mask: all lanes (slot row B = s0 - 1 - j), none (row A = s0 - j), or one
-                    // of six partial masks (one v_cndmask).  <= 3 selects per row instead of 45 compare / select / shift instructions.
-                    static_assert(P == 4 && LPP == 16, "lane masks below assume four 16-lane pixels per wave");
-                    const int s0 = rv_slot(xl + D - 1 - d0);
-                    uint32_t *pa = rrow + s0, *pb = rrow + s0 - 1;
-                    auto emit = [&](auto wc) {
-                        constexpr int W4 = decltype(wc)::value;
+        // ---- right view (oracle S6): key (S<<16 | d) into slot p - (x0 - (D-1)) = xl + D-1 - d.  (Issued before the pixel record below:
+        // after it, the record's LDS reads no longer queue behind the atomics, and the sweep was 4 % SLOWER, profiles/r04_fused.txt.)
+        if (valid) {
+            uint32_t *rrow = &s_rmin[lr][0];
+            if constexpr (RVPAD) {
+                // Padded rows (rv_slot): slot of entry base - j = s0 - j - [j > b4] with b4 = (xl - 1) & 15 and xl = 4 wid + pg (P = 4 pixels
+                // per wave, 16 lanes each): the pad's carry depends on the lane only through pg = lane >> 4, and on the wave only through
+                // wid & 3.  One code version per wave class, in which every carry is a COMPILE-TIME lane mask: no lane (slot s0 - j), every
+                // lane (s0 - 1 - j), or one of six partial masks (one v_cndmask, shared by the j's with the same mask).  <= 3 selects per
+                // row instead of 45 compare / select / shift instructions (246 instead of 288 VALU per wave-step): the D=256 / 4-path
+                // sweep 1.36 -> 1.29 ms per 16 frames, means of five alternating runs (profiles/r04_fused.txt).
+                static_assert(P == 4 && LPP == 16, "lane masks below assume four 16-lane pixels per wave");
+                const int s0 = rv_slot(xl + D - 1 - d0);
+                auto emit = [&](auto wc) {
+                    constexpr int W4 = decltype(wc)::value;
+                    const int ia = s0, ib = s0 - 1;
+                    int base = ia;                     // s0 or s0 - 1 per lane: an INDEX into the row (the select works on 32-bit values, never on pointers)
+                    unsigned long long prev = 0;       // the carry mask `base` was made for: masks only grow with j, so equal masks are adjacent
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            unsigned long long mask = 0;   // lanes whose slot carries the pad: j > b4(pg)
+                    for (int j = 0; j < 16; ++j) {
+                        unsigned long long mask = 0;   // lanes whose slot carries the pad: j > b4(pg)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (j > ((4 * W4 + q - 1) & 15)) mask |= 0xffffull << (16 * q);
-                            uint32_t *pj;
-                            if (mask == 0) pj = pa;
-                            else if (mask == ~0ull) pj = pb;
-                            else {
-                                uint32_t lo = (uint32_t)(uintptr_t)pa, hi = (uint32_t)(uintptr_t)pb, sel;   // LDS addresses are 32-bit
-                                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(lo), "v"(hi), "s"(mask));
-                                pj = (uint32_t *)(uintptr_t)sel;
-                            }
-                            const int q = j < 8 ? j / 2 : 4 + (j - 8) / 2;   // sm[q] holds local disparities (2q', 2q'+1), low / high half
-                            const uint32_t keyv = (j & 1) ? ((sm[q] & 0xffff0000u) | (uint32_t)(d0 + j)) : ((sm[q] << 16) | (uint32_t)(d0 + j));
-                            atomicMin(pj - j, keyv);
+                        for (int q = 0; q < 4; ++q)
+                            if (j > ((4 * W4 + q - 1) & 15)) mask |= 0xffffull << (16 * q);
+                        if (mask != prev) {
+                            if (mask == ~0ull) base = ib;
+                            // The lane mask goes into VCC as two 32-bit halves.  Handed over as ONE 64-bit "s" operand, the compiler
+                            // rematerialises it with s_mov_b64 and a 32-bit literal, and 0x00000000ffff0000 and 0xffffffffffff0000 then
+                            // share one encoding (literal 0xffff0000): the last two rows of every sweep came out wrong that way.
+                            else asm volatile("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32 %0, %1, %2, vcc"
+                                              : "=v"(base) : "v"(ia), "v"(ib), "i"((int)(uint32_t)mask), "i"((int)(uint32_t)(mask >> 32)) : "vcc");
+                            prev = mask;
                         }
-                    };
-                    switch (wid & 3) {   // wave-uniform
-                        case 0: emit(std::integral_constant<int, 0>{}); break;
-                        case 1: emit(std::integral_constant<int, 1>{}); break;
-                        case 2: emit(std::integral_constant<int, 2>{}); break;
-                        default: emit(std::integral_constant<int, 3>{}); break;
+                        const int q = j < 8 ? j / 2 : 4 + (j - 8) / 2;   // sm[q] holds local disparities (2q', 2q'+1), low / high half
+                        const uint32_t keyv = (j & 1) ? ((sm[q] & 0xffff0000u) | (uint32_t)(d0 + j)) : ((sm[q] << 16) | (uint32_t)(d0 + j));
+                        atomicMin(rrow + (base - j), keyv);   // - j rides on the instruction's immediate offset
                     }
-                    return;
+                };
+                switch (wid & 3) {   // wave-uniform
+                    case 0: emit(std::integral_constant<int, 0>{}); break;
+                    case 1: emit(std::integral_constant<int, 1>{}); break;
+                    case 2: emit(std::integral_constant<int, 2>{}); break;
+                    default: emit(std::integral_constant<int, 3>{}); break;
                 }
-#endif
-                const int base = xl + D - 1 - d0, s0 = RVPAD ? rv_slot(base) : base;
-                int b4 = base & 15;
-                if constexpr (RVPAD) asm volatile("" : "+v"(b4));   // recompute the 16 slots every row: hoisted, they spill
+            } else {
+                const int s0 = xl + D - 1 - d0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int da = q < 4 ? 2 * q : 8 + 2 * (q - 4);  // local disparity of the low half of sm[q]
-                    atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da) : s0 - da), (sm[q] << 16) | (uint32_t)(d0 + da));
-                    atomicMin(rrow + (RVPAD ? rv_slot_below(s0, b4, da + 1) : s0 - da - 1), (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
+                    atomicMin(rrow + s0 - da, (sm[q] << 16) | (uint32_t)(d0 + da));
+                    atomicMin(rrow + s0 - da - 1, (sm[q] & 0xffff0000u) | (uint32_t)(d0 + da + 1));
                 }
             }
-        };
-        if (!CART_F_RVLAST) right_view();
+        }
         // No block barrier: the tile rows a lane reads below are its own pixel's, written by lanes of the same wave (LDS
         // operations of one wave execute in order); the block-wide arrays (s_rmin, s_rec) are only read in the burst.
         // The pixel's first lane records (best d, unique?, best cost | neighbour costs); the sub-pixel division is
@@ -1595,7 +1539,6 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
             const uint32_t unique = (int)tot == tot_nbr ? 1u : 0u;
             s_rec[lr][xl] = make_uint2((uint32_t)bd | (unique << 8) | ((uint32_t)bc << 9), (uint32_t)l | ((uint32_t)rr << 16));
         }
-        if (CART_F_RVLAST) right_view();
     };
 
     // one pipelined iteration: WTA of sweep step r (image row h-1-r) + path costs of step r+1
@@ -1604,14 +1547,7 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
 #pragma unroll
         for (int i = 0; i < 8; ++i) sp[i] = st[i];
         agg(g.h - 2 - r_);
-        if (CART_FUSED_ABLATE & 256) {   // timing experiment: no WTA (keeps the slab loads alive through the state)
-            constexpr int SET = decltype(set_c)::value;
-#pragma unroll
-            for (int k = 0; k < NP - 1; ++k) st[k & 7] ^= (r.sv[SET][k][0] ^ r.sv[SET][k][1] ^ r.sv[SET][k][2] ^ r.sv[SET][k][3]) & 1u;
-            load_slab_row(max(g.h - 3 - r_, 0), set_c);
-        } else {
-            wta(sp, lr, g.h - 1 - r_, set_c);
-        }
+        wta(sp, lr, g.h - 1 - r_, set_c);
     };
 
     // Burst of the buffered rows (LDS row r holds image row ytop + nrows-1-r).  Stores inside the row loop would sit
@@ -1623,8 +1559,7 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
     // the prefetches issued before the burst and their use after it and waits for everything, including the
     // acknowledgement of the burst's own stores: ~13 us per burst, 0.3 ms per 16-frame launch.
     auto flush = [&](int t0, int nrows) {   // LDS row r = sweep step t0 + r = image row h-1-t0-r
-        if (CART_FUSED_ABLATE & 512) return;   // timing experiment: no burst
-        if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();   // 2048: burst without its two barriers
+        lds_barrier();
         // partial rows hold u16 keys (rv_key16): NRP / 2 dwords per row
         uint32_t *pbase = a.partial + (((size_t)frame * nblk + blk) * (size_t)hpad + t0) * (NRP / 2);
 #pragma unroll
@@ -1645,7 +1580,7 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
             const bool live = r < nrows && x0 + c < g.w && i0 + (int)threadIdx.x < RB * COLS;
             uint16_t *dst = live ? a.wta_l + (size_t)frame * g.npx + (size_t)(g.h - 1 - t0 - r) * g.w + x0 + c
                                  : reinterpret_cast<uint16_t *>(pbase) + NRP - 1;   // the spare slot of the chunk's first row
-            if (!(CART_FUSED_ABLATE & 16)) *dst = (uint16_t)out;
+            *dst = (uint16_t)out;
         }
         static_assert(RB * NRP % 8 == 0, "a lane packs eight right-view slots into one 16-byte store");
 #pragma unroll
@@ -1663,9 +1598,9 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
             }
             v4u *dst = live ? reinterpret_cast<v4u *>(pbase) + i
                             : reinterpret_cast<v4u *>(a.partial + (((size_t)frame * nblk + blk + 1) * (size_t)hpad) * (NRP / 2)) - 1;
-            if (!(CART_FUSED_ABLATE & 8)) *dst = v;
+            *dst = v;
         }
-        if (!(CART_FUSED_ABLATE & 2048)) lds_barrier();
+        lds_barrier();
     };
 
     __syncthreads();
@@ -1704,17 +1639,29 @@ __global__ __launch_bounds__(64 * WPB_, fused_minw(NP)) void wta_fused_kernel(Fu
 
 // right_pk[p] = min over the blocks whose p-range [blk*COLS - (D-1), blk*COLS + COLS - 1] holds p.
 // partial = [frame][block][sweep step t = h-1-y][rv_row_slots u16 keys] (rows padded, see wta_fused_kernel's flush)
-__global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int D, int cols, int nblk, int padded) {
+// At most NB = ceil((D-1)/COLS) + 1 blocks cover a right pixel (17 at D = 256 with 16-column blocks): all NB keys are requested at once,
+// out-of-range blocks clamped onto the first one and masked, so that the loads do not wait for each other (as a loop over b0..b1 the
+// merge took 0.14 ms per 16-frame launch at D = 256 / 4 paths: a tenth of the sweep it follows).
+template <int D, int COLS, bool PADDED>
+__global__ __launch_bounds__(256) void rv_merge_kernel(const uint32_t *partial, uint32_t *right_pk, int w, int h, int nblk) {
+    constexpr int NB = (D - 1 + COLS - 1) / COLS + 1, NRP = rv_row_slots(COLS, D, PADDED);
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), frame = blockIdx.z;
     if (p >= w || y >= h) return;
-    const int nrp = rv_row_slots(cols, D, padded != 0), hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
-    const uint16_t *keys = reinterpret_cast<const uint16_t *>(partial);
-    const int b0 = p / cols, b1 = min((p + D - 1) / cols, nblk - 1);
+    const int hpad = (h + kFusedRB - 1) / kFusedRB * kFusedRB + kFusedRB;
+    const uint16_t *keys = reinterpret_cast<const uint16_t *>(partial) + ((size_t)frame * nblk * hpad + (size_t)(h - 1 - y)) * NRP;
+    const int b0 = p / COLS, b1 = min((p + D - 1) / COLS, nblk - 1);
+    uint32_t k[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int b = min(b0 + i, b1);
+        const int e = p - (b * COLS - (D - 1));
+        k[i] = keys[(size_t)b * hpad * NRP + (PADDED ? rv_slot(e) : e)];
+    }
     uint32_t best = 0xffffffffu;
-    for (int b = b0; b <= b1; ++b) {
-        const int e = p - (b * cols - (D - 1));
-        const uint32_t k = keys[(((size_t)frame * nblk + b) * hpad + (h - 1 - y)) * nrp + (padded ? rv_slot(e) : e)];
-        if (k != 0xffffu) best = min(best, rv_key32(k, e, cols, D));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int b = min(b0 + i, b1);   // (a clamped duplicate of the last block changes nothing)
+        if (k[i] != 0xffffu) best = min(best, rv_key32(k[i], p - (b * COLS - (D - 1)), COLS, D));
     }
     right_pk[((size_t)frame * h + y) * w + p] = best;
 }
@@ -1739,7 +1686,7 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTa
             case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 4>), grid, block, 0, s, a); break;
             case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 4>), grid, block, 0, s, a); break;
             default:
-                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 4, 2 * CART_FUSED_WAVES_16>), grid, block, 0, s, a);
+                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 4, 2 * fused_waves(16)>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((wta_fused_kernel<16, 4>), grid, block, 0, s, a);
                 break;
         }
@@ -1748,13 +1695,19 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTa
             case 64: hipLaunchKernelGGL((wta_fused_kernel<4, 8>), grid, block, 0, s, a); break;
             case 128: hipLaunchKernelGGL((wta_fused_kernel<8, 8>), grid, block, 0, s, a); break;
             default:
-                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 8, 2 * CART_FUSED_WAVES_16>), grid, block, 0, s, a);
+                if (wide) hipLaunchKernelGGL((wta_fused_kernel<16, 8, 2 * fused_waves(16)>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((wta_fused_kernel<16, 8>), grid, block, 0, s, a);
                 break;
         }
     }
-    hipLaunchKernelGGL(rv_merge_kernel, dim3((g.w + 63) / 64, (g.h + 3) / 4, n_frames), dim3(256), 0, s, (const uint32_t *)partial, right_pk,
-                       g.w, g.h, g.D, cols, nblk, fused_rv_padded(g) ? 1 : 0);
+    const dim3 mgrid((g.w + 63) / 64, (g.h + 3) / 4, n_frames), mblock(256);
+    const bool padded = fused_rv_padded(g);
+#define CART_MERGE(DD, CC, PP) hipLaunchKernelGGL((rv_merge_kernel<DD, CC, PP>), mgrid, mblock, 0, s, (const uint32_t *)partial, right_pk, g.w, g.h, nblk)
+    if (g.D == 64) CART_MERGE(64, 32, false);
+    else if (g.D == 128) CART_MERGE(128, 16, false);
+    else if (cols == 32) { if (padded) CART_MERGE(256, 32, true); else CART_MERGE(256, 32, false); }
+    else { if (padded) CART_MERGE(256, 16, true); else CART_MERGE(256, 16, false); }
+#undef CART_MERGE
 }
 
 // ------------------------------------------------------------------ median x2 + LR check + range fix
