@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
     ch = rng.choice((1, 1, 3)); scene = rng.choice(synth.SCENES); s = rng.randint(0, 1 << 30)
     desc = f"w={w} h={h} D={D} P={P} md={md} p1={p1} p2={p2} uniq={uniq} r={radius} it={iters} var={variants} plan={plan} B={B} chunk={chunk} ch={ch} scene={scene} seed={s}"
     # a third of the cases tune the slab placement first (cart_engine_tune_placement: the workspace is swapped for another one); some give the
-    # engine more slots than the call needs, large cases up to a workspace above 8 GiB (several physical allocations behind one address range)
+    # engine more slots than the call needs, large cases up to a workspace above 8 GiB (several slot groups, each its own hipMalloc)
     inflight = B
     if rng.random() < 0.3:
         inflight = B + rng.randint(1, 24)

@@ -13,7 +13,7 @@ steps = int(os.environ.get("STEPS", 400))
 eng = Engine(w, h, num_disparities=D, paths=P, min_disparity=4, smoothing_radius=2, smoothing_iterations=1, max_inflight=2 * B)
 if os.environ.get("PLAN"):   # PLAN=pairs | fused_up | slabs: soak one launch plan (all must reproduce the first step bit for bit)
     eng.set_plan(os.environ["PLAN"])
-if os.environ.get("TUNE", "1") != "0":   # the product set-up: a fast placement of the slab workspace (several physical allocations behind one range)
+if os.environ.get("TUNE", "1") != "0":   # the product set-up: a fast placement of the slab workspace (slot groups of at most 8 GiB, each its own hipMalloc)
     print("tune_placement: %.3f -> %.3f ms" % eng.tune_placement(B, 10), flush=True)
 pipe = StereoPipeline(eng, provider="histogram_peak", with_ccl=True, overlap=True)
 ls, rs = synth.make_batch(4, w, h, D, 4)
