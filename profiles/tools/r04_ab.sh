@@ -19,6 +19,9 @@ CFG[c2]=""
 CFG[d256p8]="--disparities 256 --paths 8"
 CFG[c2f32]="--plan fused_up --batch 32 --chunk 32"
 CFG[c3p4]="--width 1920 --height 1080 --disparities 256 --paths 4 --batch 4"
+CFG[ref6]="--disparities 256 --paths 4 --batch 6"
+CFG[c2b12]="--batch 12"
+CFG[c1]="--disparities 64 --paths 4"
 CFG[ref32]="--disparities 256 --paths 4 --batch 32 --chunk 32"
 for r in $(seq $ROUNDS); do
   for c in ${CONFIGS:-ref c3 c2f d256p8}; do
