@@ -90,6 +90,7 @@ PROTOTYPES = {
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),
     "cart_debug_uniq_table": (_i, [_vp, _i, C.POINTER(C.c_uint16)]),
+    "cart_debug_slab_layout": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "cart_engine_set_timing": (_i, [_vp, _i]),
     "cart_engine_collect_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "cart_engine_version": (C.c_char_p, []),

@@ -366,6 +366,12 @@ class Engine:
                     "cart_debug_read")
         return buf
 
+    def slab_layout(self):
+        """cart_debug_slab_layout -> dict(group_slots, groups, slot_bytes, group_bytes): how the cost-slab workspace is cut into device allocations."""
+        gs, ng, sb, gb = C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self._lib.cart_debug_slab_layout(self._h, C.byref(gs), C.byref(ng), C.byref(sb), C.byref(gb)), "cart_debug_slab_layout")
+        return {"group_slots": gs.value, "groups": ng.value, "slot_bytes": sb.value, "group_bytes": gb.value}
+
     def set_timing(self, enabled=True):
         self._check(self._lib.cart_engine_set_timing(self._h, 1 if enabled else 0), "cart_engine_set_timing")
 

@@ -1464,6 +1464,17 @@ int cart_find_plane_params(const int32_t hist[256], cart_plane_params *io) {
     return 1;
 }
 
+int cart_debug_slab_layout(cart_engine *e, int *group_slots, int *n_groups, size_t *slot_bytes, size_t *group_bytes) {
+    if (!e) return fail("engine is NULL");
+    if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
+    const SlabPool &sp = e->slab_pool;
+    if (group_slots) *group_slots = sp.group_slots;
+    if (n_groups) *n_groups = sp.groups();
+    if (slot_bytes) *slot_bytes = sp.slot_bytes;
+    if (group_bytes) *group_bytes = sp.bytes_of(0);
+    return 0;
+}
+
 int cart_debug_uniq_table(cart_engine *e, int uniqueness_ratio, uint16_t *out2048) {
     if (!out2048) return fail("bad arguments");
     if (uniqueness_ratio < 0 || uniqueness_ratio > 100) return fail("uniqueness_ratio must be in [0, 100]");

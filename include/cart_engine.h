@@ -367,6 +367,10 @@ int cart_debug_read(cart_engine *engine, int frame_slot, int what, void *host_ds
  * compiled for the host.  out2048 is a HOST array. */
 int cart_debug_uniq_table(cart_engine *engine, int uniqueness_ratio, uint16_t *out2048);
 
+/* Test / diagnostic access to the layout of the cost-slab workspace: the slots are cut into groups, each group one
+ * device allocation of at most 8 GiB - 64 MiB.  Any pointer may be NULL.  group_bytes: bytes of a full group (the last one may be smaller). */
+int cart_debug_slab_layout(cart_engine *engine, int *group_slots, int *n_groups, size_t *slot_bytes, size_t *group_bytes);
+
 /* Per-stage device time (hipEvents recorded on the caller's stream around each stage of
  * cart_compute_disparity[_batch]).  set_timing(1) enables recording and clears the record ring
  * (the last 256 calls are kept); collect_timing() synchronises the device and returns, per stage,

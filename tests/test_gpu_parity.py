@@ -1147,6 +1147,27 @@ def test_placement_tuning_keeps_the_bits(torch_cuda, D, P, inflight, cap):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,D,P,inflight,want_slots,want_groups", [
+    (1242, 375, 128, 8, 40, 16, 3),     # 477 MB per slot: 16 slots = 7.6 GB per group, 16 + 16 + 8
+    (1242, 375, 64, 4, 32, 32, 1),      # 119 MB per slot: everything in one allocation of 3.8 GB
+    (1920, 1080, 256, 8, 3, 2, 2),      # 4.25 GB per slot: two fit (7.91 GiB), three would not
+    (3840, 1200, 256, 8, 2, 1, 2),      # 9.4 GB per slot: larger than the limit by itself, one allocation per slot
+    (1242, 375, 256, 4, 12, 12, 1),     # the reference's defaults with its 12 frames in flight: one allocation of 5.7 GB
+])
+def test_slab_workspace_is_cut_into_groups_of_at_most_8_gib(torch_cuda, w, h, D, P, inflight, want_slots, want_groups):
+    """no device allocation behind the cost slabs exceeds 8 GiB - 64 MiB (the aggregation launch is always in its slow
+    mode above 8 GiB, profiles/r03_alloc.txt), groups hold a multiple of 16 slots from 16 up, and a slot that is larger than the limit by
+    itself still gets one allocation."""
+    eng = make_engine(w, h, D, P, 4, inflight=inflight)
+    lay = eng.slab_layout()
+    assert lay["slot_bytes"] == w * h * D * P
+    assert (lay["group_slots"], lay["groups"]) == (want_slots, want_groups)
+    assert lay["group_bytes"] == lay["group_slots"] * lay["slot_bytes"]
+    assert lay["group_bytes"] <= (8 << 30) - (64 << 20) or lay["group_slots"] == 1
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_two_large_engines_tuned_side_by_side(torch_cuda):
     """Round-3 hazard, made unreachable: the slab workspace used to sit behind HIP virtual-memory-management calls, and ranges that were
     freed and re-reserved while others were live ended in GPU memory access faults (profiles/r04_vmm_faults.txt).  The workspace is plain
