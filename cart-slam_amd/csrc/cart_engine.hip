@@ -57,6 +57,7 @@ struct TimingRec {
 // The slab workspace: one plain hipMalloc per GROUP of workspace slots, no group larger than kSlabChunkBytes (see slab_pool_alloc).
 // Slot s lives at base[s / group_slots] + (s % group_slots) * slot_bytes; the kernels of a launch get the slab pointers of their
 // frames as a table (SlabTable), so a launch may span groups.
+static_assert(kMaxLaunchFrames == 64, "cart_engine_set_option(CART_OPT_CHUNK_FRAMES) documents 1..64");
 struct SlabPool {
     std::vector<uint8_t *> base;   // one device allocation per group
     int group_slots = 0;           // slots per group (the last group may hold fewer)
@@ -444,7 +445,7 @@ int cart_engine_set_option(cart_engine *e, int option, int value) {
             e->opt_plan_min_frames = value;
             return 0;
         case CART_OPT_CHUNK_FRAMES:
-            if (value < 1 || value > 64) return fail("chunk frames must be in [1, 64]");  // pointer-table (multi) calls stay at kLaunchFrames
+            if (value < 1 || value > kMaxLaunchFrames) return fail("chunk frames must be in [1, 64]");   // 64 = entries of the per-launch slab table (SlabTable); pointer-table (multi) calls stay at kLaunchFrames
             e->chunk_frames = value;
             return 0;
         case CART_OPT_SPEC_S8_ZERO_INVALID:
