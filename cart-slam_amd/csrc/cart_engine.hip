@@ -561,9 +561,10 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
         for (int t = 1; t < max_tries && !mine.empty(); ++t) {
             // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
             // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
-            // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 1.5 s + 1 s per 20 GB of workspace in all.
+            // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 0.25 s per allowed try + 1 s per 20 GB of workspace in all
+            // (the caller buys search time with max_tries: 3.3 s at ten tries and 15 GB).
             if (kept < 0.885f * worst) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 1.5 + (double)sp.slots * (double)sp.slot_bytes / 20e9) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 0.25 * max_tries + (double)sp.slots * (double)sp.slot_bytes / 20e9) break;
             while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
                 (void)hipFree(held.front().p);
                 extra -= held.front().bytes;
