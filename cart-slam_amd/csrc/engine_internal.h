@@ -51,6 +51,7 @@ struct AggArgs {
     int blocks_per_frame;
     int n_frames;        // filled by launch_aggregate
     int xcd_frames;      // filled by launch_aggregate: decode the grid per XCD (frames x, x + 8, ... on XCD x)
+    int hsplit;          // filled by launch_aggregate: horizontal scans run as producer / consumer wave pairs (2 P rows per workgroup)
     DirDesc dirs[kMaxPaths];
 };
 
@@ -83,7 +84,8 @@ void launch_census(const ImageBatch &left, const ImageBatch &right, int channels
                    uint8_t *gray_l, uint8_t *gray_r, uint32_t *cen_l, uint32_t *cen_r, uint32_t *right_pk,
                    const Geometry &g, hipStream_t s);
 int agg_lines_per_block(int D);  // scan lines per 256-thread block (a pixel is owned by D/16 lanes)
-int agg_residency_cap(int ndirs, int D, int n_frames);  // 4-wave aggregation workgroups allowed per CU at a time, 0 = uncapped (measured table at its definition)
+int agg_residency_cap(int ndirs, int D, int n_frames, bool hsplit = false);  // 4-wave aggregation workgroups allowed per CU at a time, 0 = uncapped (measured table at its definition)
+bool agg_hsplit(const Geometry &g, int ndirs, int n_frames);  // the launch runs its horizontal scans as producer / consumer wave pairs
 void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 // thr = device table of the integer uniqueness threshold for every best cost 0..2047 (launch_uniq_table, built once per engine)
 void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,

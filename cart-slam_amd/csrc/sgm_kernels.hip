@@ -461,16 +461,138 @@ __device__ __forceinline__ void hscan_sliding(uint32_t (&st)[8], uint32_t &mm, c
     for (int gi = 1; gi < groups; ++gi) group();
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0): at the
+// end of a burst every wave would sit out the acknowledgement of its global stores (~10 us under this read load), 23
+// times per sweep (0.3 ms per 16-frame launch).  The bursts only exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- horizontal scans split over a wave PAIR (AggArgs::hsplit) ----------------------------------------------------------
+// A horizontal scan is a chain of `width` steps on which one wave issues ~102 instructions per step and nothing can be done
+// in parallel along the row: alone on its SIMD it already uses every issue slot (1242 steps x ~445 clocks = 0.27 ms whatever
+// the launch holds), and launches with few frames -- or D = 64, where the other directions are short -- wait for these chains.
+// 40 of the 102 instructions do not depend on the recurrence at all: the matching cost (xor, popcount, pack).  In split mode a
+// PRODUCER wave keeps the sliding census window and writes the packed costs of step t+1 into LDS while the CONSUMER wave of
+// the pair runs the recurrence of step t on the costs it reads back: ~60 instructions per step on the chain instead of 102.
+// The two sit on different SIMDs of the CU (waves of a workgroup are dealt over its four SIMDs); one s_barrier per step keeps
+// them one step apart (double-buffered costs).  A 4-wave workgroup holds two pairs, i.e. 2 P rows instead of 4 P.
+constexpr int kHsCostDwords = 2 * 2 * 64 * 4;   // per pair: [buffer][half][lane][4 dwords]
+
+template <int LPP>
+__device__ __forceinline__ void agg_step_c(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&c)[8], uint32_t sel_lo, uint32_t sel_hi,
+                                           uint32_t p1p1, uint32_t p2p2, CART_GLOBAL uint8_t *po) {
+    // agg_step with the matching costs handed in: c[i] = (C[d0+8+i] << 16) + C[d0+i], the pair agg_step builds from its popcounts
+    const uint32_t mp2 = mm + p2p2;
+    const uint32_t lo0 = perm(a[7], dpp_mov<DPP_ROW_SHR1>(a[7]), sel_lo);
+    const uint32_t hi7 = perm(dpp_mov<DPP_ROW_SHL1>(a[0]), a[0], sel_hi);
+    uint32_t n[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t lo = i == 0 ? lo0 : a[i - 1];
+        const uint32_t hi = i == 7 ? hi7 : a[i + 1];
+        uint32_t t = pk_min(lo, hi) + p1p1;
+        t = pk_min3(t, a[i], mp2);
+        n[i] = (t - mm) + c[i];   // both halves of t are >= m (see agg_step)
+    }
+    uint4 o;
+    o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
+    o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u q = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);
+    uint32_t x = pk_min(pk_min3(n[0], n[1], n[2]), pk_min3(n[3], n[4], pk_min3(n[5], n[6], n[7])));
+    x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
+    mm = group_allmin<LPP>(x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = n[i];
+}
+
+// producer of a pair: costs of every step t = 0 .. w-1 into buffer t & 1, one barrier after each, one more at the end (the consumer's last step)
+template <int LPP, int DX>
+__device__ __forceinline__ void hsplit_producer(const uint32_t *pl, unsigned lo_l, const uint32_t *pr, unsigned lo_r, int w, uint32_t *cost, int lane) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    auto emit = [&](int parity, const uint32_t (&c)[8]) {
+        v4u *dst = reinterpret_cast<v4u *>(cost) + parity * 128 + lane;
+        dst[0] = v4u{c[0], c[1], c[2], c[3]};
+        dst[64] = v4u{c[4], c[5], c[6], c[7]};
+        lds_barrier();
+    };
+    const int groups = w / 16;
+    if (groups > 0) {
+        uint32_t win[16], ffl[HS_PF], fnw[HS_PF];
+        ld_u32x16(pr, lo_r, win);                          // window of step 0
+        unsigned lo_n = lo_r + (DX > 0 ? 15u * 4u : 0u);   // the element that enters the window (see hscan_sliding)
+#pragma unroll
+        for (int q = 0; q < HS_PF; ++q) {
+            ffl[q] = ld_u32(pl + q * DX, lo_l);
+            fnw[q] = ld_u32(pr + (q + 1) * DX, lo_n);
+        }
+        auto group = [&]() {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int slot = j % HS_PF;
+                const uint32_t f = ffl[slot];
+                uint32_t c[8];   // c[i] = (C[d0+8+i] << 16) + C[d0+i]: logical window slot k of this sub-step is register (k +- j) & 15
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    c[i] = ((uint32_t)__builtin_popcount(f ^ win[(DX > 0 ? 7 - i + j : 7 - i - j + 16) & 15]) << 16) +
+                           (uint32_t)__builtin_popcount(f ^ win[(DX > 0 ? 15 - i + j : 15 - i - j + 16) & 15]);
+                win[(DX > 0 ? j : 15 - j) & 15] = fnw[slot];
+                ffl[slot] = ld_u32(pl + (j + HS_PF) * DX, lo_l);          // step j + HS_PF (reads row padding past the end)
+                fnw[slot] = ld_u32(pr + (j + HS_PF + 1) * DX, lo_n);
+                emit(j & 1, c);
+            }
+            pl += 16 * DX; pr += 16 * DX;
+        };
+        group();
+        for (int gi = 1; gi < groups; ++gi) group();
+    }
+    for (int t = groups * 16; t < w; ++t) {   // the last w % 16 steps: plain loads
+        CensusRegs cr;
+        load_census(pl, lo_l, pr, lo_r, cr);
+        uint32_t c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            c[i] = ((uint32_t)__builtin_popcount(cr.fl ^ cr.r[7 - i]) << 16) + (uint32_t)__builtin_popcount(cr.fl ^ cr.r[15 - i]);
+        emit(t & 1, c);
+        pl += DX; pr += DX;
+    }
+    lds_barrier();
+}
+
+template <int LPP>
+__device__ __forceinline__ void hsplit_consumer(uint32_t (&st)[8], uint32_t &mm, uint8_t *po, unsigned lo_o, ptrdiff_t ostride, int w, const uint32_t *cost,
+                                                int lane, uint32_t sel_lo, uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    auto step = [&](int parity, uint8_t *dst) {
+        const v4u *src = reinterpret_cast<const v4u *>(cost) + parity * 128 + lane;
+        const v4u c0 = src[0], c1 = src[64];
+        const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        agg_step_c<LPP>(st, mm, c, sel_lo, sel_hi, p1p1, p2p2, sgpr(dst) + pin_v(lo_o));
+        lds_barrier();
+    };
+    lds_barrier();   // the costs of step 0 are in buffer 0
+    int t = 0;
+    for (; t + 1 < w; t += 2) {
+        step(0, po);
+        step(1, po + ostride);
+        po += 2 * ostride;
+    }
+    if (t < w) step(0, po);
+}
+
 // prefetch depth of the vertical / diagonal scans in steps (see the note at the loop): 4 at D = 64 (-10 %), 2 elsewhere (flat)
 template <int LPP> constexpr int v_depth() { return LPP == 4 ? 4 : 2; }
 
 constexpr int kAggWaves = 4;   // waves per workgroup: nothing in the kernel is shared between waves (1-2: 1.85 instead of 1.58 ms at the headline; 8: slower but at D=64)
-template <int LPP>
-__global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_kernel(AggArgs a) {
+// HS: the launch runs its horizontal scans as producer / consumer wave pairs (hsplit_*); a separate instantiation, so that the plain launch keeps its
+// 70 VGPRs (7 waves per SIMD) and the split one gets the registers its producer needs without spilling
+template <int LPP, bool HS = false>
+__global__ __launch_bounds__(64 * kAggWaves, (LPP >= 8 && !HS) ? 6 : 4) void aggregate_kernel(AggArgs a) {
     using WN = Win<LPP>;
     constexpr int P = WN::P;
     constexpr int LINES_PER_BLOCK = kAggWaves * P;
     __shared__ uint32_t s_win[kAggWaves][2][WN::BUF];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cost[HS ? kAggWaves / 2 : 1][HS ? kHsCostDwords : 4];   // split horizontal scans: the pairs' cost buffers
     const Geometry &g = a.g;
     // 1-D grid, direction-major: [dir][frame][line group].  The horizontal directions come first so that
     // their W-step serial scans of EVERY frame start at once; the H-step scans fill in behind them.
@@ -484,17 +606,19 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
     int di = 0;
     for (int i = 1; i < a.ndirs; ++i)
         if (bid >= a.dirs[i].blk0 * nfr) di = i;
-    const int nblk = (a.dirs[di].nlines + LINES_PER_BLOCK - 1) / LINES_PER_BLOCK;
+    const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
+    const bool hsplit = HS && dy == 0;   // this workgroup runs two producer / consumer pairs on 2 P rows (launch_aggregate counted its blocks that way)
+    const int lpb = hsplit ? 2 * P : LINES_PER_BLOCK;
+    const int nblk = (a.dirs[di].nlines + lpb - 1) / lpb;
     const int rb = bid - a.dirs[di].blk0 * nfr;
     const int frame = frame0 + fstep * (rb / nblk);
     const int bl = rb - (rb / nblk) * nblk;   // block inside the frame's share of this direction
-    const int dx = a.dirs[di].dx, dy = a.dirs[di].dy;
     const int lane = threadIdx.x & 63, wid = uniform((int)(threadIdx.x >> 6));
     const int gl = lane % LPP, pg = lane / LPP;  // lane inside the pixel's lane group, pixel group inside the wave
-    const int line0 = bl * LINES_PER_BLOCK + wid * P;  // wave-uniform
+    const int line0 = bl * lpb + (hsplit ? wid >> 1 : wid) * P;  // wave-uniform
     const int line = line0 + pg;
     const int nlines = a.dirs[di].nlines;
-    if (line0 >= nlines) return;  // whole wave idle
+    if (line0 >= nlines && !hsplit) return;  // whole wave idle (a split-scan workgroup keeps all four waves: they meet at a barrier every step)
     const int d0 = gl * 16;
     const uint32_t p1p1 = (uint32_t)g.p1 * 0x10001u, p2p2 = (uint32_t)g.p2 * 0x10001u;
     // selectors of the two stitching v_perm: 0x0d bytes inject 0xFFFF where d-1 / d+1 leave [0, D)
@@ -516,6 +640,25 @@ __global__ __launch_bounds__(64 * kAggWaves, LPP >= 8 ? 6 : 4) void aggregate_ke
         // ---- horizontal scans: the wave's pixels sit on P different rows, nothing to share; per-lane loads.
         // These waves carry the longest dependency chain of the launch: let them win VALU arbitration.
         __builtin_amdgcn_s_setprio(3);
+        if constexpr (HS) {
+            // rows past the image (the last wave pair of a direction) clone the pair's last valid row: same reads, same bytes to the same cells,
+            // and every wave that entered reaches every barrier
+            const int l0 = min(line0, nlines - 1), pgv = min(pg, nlines - l0 - 1);   // (a pair wholly past the image clones the last row)
+            const int y0s = a.dirs[di].jmin + l0, xs = dx > 0 ? 0 : g.w - 1;
+            const uint32_t *pls = a.cen_l + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0s * g.cpitch + g.cpadl + xs);
+            const uint32_t *prs = a.cen_r + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0s * g.cpitch + g.cpadl + xs - g.min_disp - (WN::D - 1));
+            uint8_t *pos = a.slabs.frame[frame] + uniform((ptrdiff_t)a.dirs[di].path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0s * g.w + xs) * g.D);
+            const unsigned so_l = (unsigned)pgv * g.cpitch * 4u, so_r = so_l + (unsigned)(WN::D - 16 - d0) * 4u;
+            const unsigned so_o = (unsigned)pgv * g.w * g.D + d0;
+            uint32_t *cost = &s_cost[wid >> 1][0];
+            if ((wid & 1) == 0) {
+                if (dx > 0) hsplit_producer<LPP, 1>(pls, so_l, prs, so_r, g.w, cost, lane);
+                else hsplit_producer<LPP, -1>(pls, so_l, prs, so_r, g.w, cost, lane);
+            } else {
+                hsplit_consumer<LPP>(st, mm, pos, so_o, (ptrdiff_t)dx * g.D, g.w, cost, lane, sel_lo, sel_hi, p1p1, p2p2);
+            }
+            return;
+        }
         if (line >= nlines) return;
         const int y0r = a.dirs[di].jmin + line0;          // row of the wave's first line (uniform)
         const int x = dx > 0 ? 0 : g.w - 1, t1 = g.w;
@@ -707,15 +850,38 @@ bool xcd_placement(const Geometry &g, int n_frames) {
 //     D <= 128, fewer than 16 frames (the frame loop's coalesced groups): 4.73-4.88 k pairs/s against 4.54-4.61 k                              -> 4
 //     D <= 128, 16 frames (the headline): 1.574 / 1.547 / 1.540 / 1.60 / 1.69 alone, but beside the second stream's plane kernels the cap
 //       costs 1 % (1.61-1.68 against 1.59-1.63)                                                                                                  -> none
-int agg_residency_cap(int ndirs, int D, int n_frames) {
-    if (ndirs <= 4) return D <= 64 ? 2 : D <= 128 ? 3 : 4;
+//   split horizontal scans (round 4, pairs/s at 2 / 3 / 4 per CU): D = 256 P = 4, 6 frames 5 128 / 5 382 / 5 072, 8 frames 5 134 / 5 360 / 5 332, 12 frames
+//     5 428 / 5 542 / 5 565 -> 3;  D = 64 P = 4, 16 frames 15 407 / 14 984 / 14 227, 8 frames 12 853 / 12 337 / 11 789 -> 2 (as without the split)
+int agg_residency_cap(int ndirs, int D, int n_frames, bool hsplit) {
+    if (ndirs <= 4) return D <= 64 ? 2 : D <= 128 ? 3 : hsplit ? 3 : 4;
     return (D >= 256 || n_frames < 16) ? 4 : 0;
+}
+
+// When the horizontal scans run as producer / consumer wave pairs (hsplit_*).  They pay where the launch waits for its W-step chains --
+// few directions beside them, or few frames -- and cost 1-2 % where the launch has enough other work (profiles/r04_hsplit.txt; aggregate ms per
+// launch, plain / split, means of three alternating runs, 1242x375 unless noted):
+//   D = 64  P = 4:  16 frames 0.598 / 0.548   8 frames 0.482 / 0.339   4 frames 0.292 / 0.248
+//   D = 256 P = 4:  16 frames 1.210 / 1.230   12 frames 0.984 / 0.962   8 frames 0.796 / 0.651   6 frames 0.701 / 0.553   1920x1080, 4 frames 1.493 / 1.448
+//   D = 128 P = 8:  16 frames 1.453 / 1.456   12 frames 1.147 / 1.166   8 frames 0.782 / 0.785   4 frames 0.473 / 0.451      D = 128 P = 4, 16 frames 0.844 / 0.862
+bool agg_hsplit(const Geometry &g, int ndirs, int n_frames) {
+    return ndirs <= 4 ? (g.D == 64 || n_frames <= 12) : n_frames < 8;
 }
 
 void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     AggArgs a = a_in;
     a.n_frames = n_frames;
     a.xcd_frames = xcd_placement(a.g, n_frames) ? 1 : 0;
+    a.hsplit = agg_hsplit(a.g, a.ndirs, n_frames) ? 1 : 0;
+    {   // blocks per direction: 4 P lines each, 2 P for the horizontal directions in split mode
+        const int lpb_full = agg_lines_per_block(a.g.D);
+        int blk = 0;
+        for (int i = 0; i < a.ndirs; ++i) {
+            const int l = a.hsplit && a.dirs[i].dy == 0 ? lpb_full / 2 : lpb_full;
+            a.dirs[i].blk0 = blk;
+            blk += (a.dirs[i].nlines + l - 1) / l;
+        }
+        a.blocks_per_frame = blk;
+    }
     dim3 grid(a.blocks_per_frame * n_frames), block(64 * kAggWaves);
     // A cap on the workgroups resident per CU (agg_residency_cap above), enforced with unused dynamic LDS: the others are
     // dispatched as slots free up.  With everything resident at once (7 waves per SIMD fit) the CUs that hold the W-step
@@ -724,11 +890,19 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     // and the census planes the directions re-read stay in L2.  Smaller workgroups are slower (two waves or one: the headline's
     // launch 1.85 instead of 1.58 ms), eight-wave ones too except at D=64.
     constexpr int kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
-    const int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
+    const int resident = agg_residency_cap(a.ndirs, a.g.D, n_frames, a.hsplit != 0) * 4 / kAggWaves;   // the rule counts 4-wave workgroups
     const int lpp = a.g.D / 16;
-    const size_t static_lds = sizeof(uint32_t) * kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF);
+    const size_t static_lds = sizeof(uint32_t) * (kAggWaves * 2 * (lpp == 4 ? Win<4>::BUF : lpp == 8 ? Win<8>::BUF : Win<16>::BUF) + (a.hsplit ? (kAggWaves / 2) * kHsCostDwords : 4));
     // (never more than 64 KB per workgroup in all, the limit that needs no opt-in: two of those per CU are still two)
     const size_t pad = resident ? std::min<size_t>(kLdsPerCu / resident - kLdsGranule, 64 * 1024) - static_lds : 0;
+    if (a.hsplit) {
+        switch (a.g.D) {
+            case 64: hipLaunchKernelGGL((aggregate_kernel<4, true>), grid, block, pad, s, a); break;
+            case 128: hipLaunchKernelGGL((aggregate_kernel<8, true>), grid, block, pad, s, a); break;
+            default: hipLaunchKernelGGL((aggregate_kernel<16, true>), grid, block, pad, s, a); break;
+        }
+        return;
+    }
     switch (a.g.D) {
         case 64: hipLaunchKernelGGL(aggregate_kernel<4>, grid, block, pad, s, a); break;
         case 128: hipLaunchKernelGGL(aggregate_kernel<8>, grid, block, pad, s, a); break;
@@ -736,10 +910,6 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
     }
 }
 
-// Block barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0): at the
-// end of a burst every wave would sit out the acknowledgement of its global stores (~10 us under this read load), 23
-// times per sweep (0.3 ms per 16-frame launch).  The bursts only exchange data through LDS.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ------------------------------------------------------------------ pair sweeps (launch plan PAIRS)
 // A vertical direction and the diagonal that leans the same way ({down, down-right} or {up, up-right}) are carried by ONE

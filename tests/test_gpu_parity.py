@@ -72,6 +72,28 @@ def test_sgm_stage_by_stage(torch_cuda, w, h, D, P, md):
     eng.close()
 
 
+@pytest.mark.parametrize("w,h,D,P", [(173, 67, 128, 8), (333, 35, 64, 4), (97, 29, 256, 4), (1242, 375, 64, 4)])
+def test_split_horizontal_scans_equal_plain_ones(torch_cuda, w, h, D, P):
+    """The aggregation launch runs its horizontal scans as producer / consumer wave pairs when it would otherwise wait for their W-step
+    chains (agg_hsplit: few frames, or few directions), and as plain one-wave scans otherwise.  The same frame alone (split) and inside a
+    16-frame batch (plain, for 8 paths; D=64 / 4 paths stays split: both calls are then compared with the oracle only) must leave the
+    same horizontal slabs, cell for cell, and the oracle's -- on widths that are no multiple of 16 (the producer's tail steps) and heights
+    that leave the last workgroup a partial pair and an idle pair (rows cloned, every wave at every barrier)."""
+    torch = torch_cuda
+    ls, rs = synth.make_batch(16, w, h, D, 4, scene="stripes")
+    eng = make_engine(w, h, D, P, 4, inflight=16, plan="slabs")
+    cl, cr = O.census(ls[5]), O.census(rs[5])
+    want = {i: O.aggregate_path(cl, cr, D, 4, 10, 120, *O.path_dir(i)) for i in (2, 3)}   # right, left
+    eng.compute_disparity(dev(torch, ls[5:6]), dev(torch, rs[5:6]))
+    alone = {i: eng.debug_read(16 + i, frame_slot=0) for i in (2, 3)}
+    eng.compute_disparity(dev(torch, ls), dev(torch, rs))
+    batched = {i: eng.debug_read(16 + i, frame_slot=5) for i in (2, 3)}
+    for i in (2, 3):
+        assert (alone[i] == want[i]).all(), f"path {i}, one frame: {int((alone[i] != want[i]).sum())} cells differ"
+        assert (batched[i] == want[i]).all(), f"path {i}, 16 frames: {int((batched[i] != want[i]).sum())} cells differ"
+    eng.close()
+
+
 def test_bgr_pitched_batched(torch_cuda):
     """BGR input (fused gray conversion), non-tight pitches, a batch of frames, smoothing on."""
     torch = torch_cuda
