@@ -477,10 +477,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // them one step apart (double-buffered costs).  A 4-wave workgroup holds two pairs, i.e. 2 P rows instead of 4 P.
 constexpr int kHsCostDwords = 2 * 2 * 64 * 4;   // per pair: [buffer][half][lane][4 dwords]
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 template <int LPP>
-__device__ __forceinline__ void agg_step_c(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&c)[8], uint32_t sel_lo, uint32_t sel_hi,
-                                           uint32_t p1p1, uint32_t p2p2, CART_GLOBAL uint8_t *po) {
-    // agg_step with the matching costs handed in: c[i] = (C[d0+8+i] << 16) + C[d0+i], the pair agg_step builds from its popcounts
+__device__ __forceinline__ v4u agg_step_c(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&c)[8], uint32_t sel_lo, uint32_t sel_hi,
+                                          uint32_t p1p1, uint32_t p2p2) {
+    // agg_step with the matching costs handed in: c[i] = (C[d0+8+i] << 16) + C[d0+i], the pair agg_step builds from its popcounts;
+    // returns the lane's 16 slab bytes (the caller stores them)
     const uint32_t mp2 = mm + p2p2;
     const uint32_t lo0 = perm(a[7], dpp_mov<DPP_ROW_SHR1>(a[7]), sel_lo);
     const uint32_t hi7 = perm(dpp_mov<DPP_ROW_SHL1>(a[0]), a[0], sel_hi);
@@ -493,17 +495,13 @@ __device__ __forceinline__ void agg_step_c(uint32_t (&a)[8], uint32_t &mm, const
         t = pk_min3(t, a[i], mp2);
         n[i] = (t - mm) + c[i];   // both halves of t are >= m (see agg_step)
     }
-    uint4 o;
-    o.x = perm(n[1], n[0], 0x06040200u); o.y = perm(n[3], n[2], 0x06040200u);
-    o.z = perm(n[5], n[4], 0x06040200u); o.w = perm(n[7], n[6], 0x06040200u);
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const v4u q = {o.x, o.y, o.z, o.w};
-    __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);
+    const v4u q = {perm(n[1], n[0], 0x06040200u), perm(n[3], n[2], 0x06040200u), perm(n[5], n[4], 0x06040200u), perm(n[7], n[6], 0x06040200u)};
     uint32_t x = pk_min(pk_min3(n[0], n[1], n[2]), pk_min3(n[3], n[4], pk_min3(n[5], n[6], n[7])));
     x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
     mm = group_allmin<LPP>(x);
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = n[i];
+    return q;
 }
 
 // producer of a pair: costs of every step t = 0 .. w-1 into buffer t & 1, one barrier after each, one more at the end (the consumer's last step)
@@ -559,25 +557,50 @@ __device__ __forceinline__ void hsplit_producer(const uint32_t *pl, unsigned lo_
     lds_barrier();
 }
 
-template <int LPP>
-__device__ __forceinline__ void hsplit_consumer(uint32_t (&st)[8], uint32_t &mm, uint8_t *po, unsigned lo_o, ptrdiff_t ostride, int w, const uint32_t *cost,
-                                                int lane, uint32_t sel_lo, uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2) {
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    auto step = [&](int parity, uint8_t *dst) {
+// lanes 32..63 of `a` <-> lanes 0..31 of `b` (gfx950's v_permlane32_swap): a = {a.lo, b.lo}, b = {a.hi, b.hi}
+__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+// consumer of a pair.  D = 64 (LPP = 4): a pixel is 64 bytes, half a 128-byte line, and a step's store would write 16 rows x 64 B; the stores of TWO
+// steps are regrouped instead (four lane-half swaps) so that each instruction writes whole lines: rows 0-7 of both steps, then rows 8-15 (lo_a / lo_b:
+// this lane's byte offsets in the two stores, from the LOWER-x pixel of the step pair).  Measured with a timing build that wrote whole KB per store:
+// aggregate 0.545 -> 0.499 ms at 1242x375 D=64 P=4, and this form reaches it (0.503); D >= 128 pixels are whole lines already and gain nothing
+// (profiles/r04_hsplit.txt).
+template <int LPP, int DX>
+__device__ __forceinline__ void hsplit_consumer(uint32_t (&st)[8], uint32_t &mm, uint8_t *po, unsigned lo_o, unsigned lo_a, unsigned lo_b, int D, int w,
+                                                const uint32_t *cost, int lane, uint32_t sel_lo, uint32_t sel_hi, uint32_t p1p1, uint32_t p2p2) {
+    const ptrdiff_t ostride = (ptrdiff_t)DX * D;
+    auto step = [&](int parity) {
         const v4u *src = reinterpret_cast<const v4u *>(cost) + parity * 128 + lane;
         const v4u c0 = src[0], c1 = src[64];
         const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        agg_step_c<LPP>(st, mm, c, sel_lo, sel_hi, p1p1, p2p2, sgpr(dst) + pin_v(lo_o));
+        const v4u q = agg_step_c<LPP>(st, mm, c, sel_lo, sel_hi, p1p1, p2p2);
         lds_barrier();
+        return q;
     };
     lds_barrier();   // the costs of step 0 are in buffer 0
     int t = 0;
     for (; t + 1 < w; t += 2) {
-        step(0, po);
-        step(1, po + ostride);
+        if constexpr (LPP == 4) {
+            const v4u s0 = step(0), s1 = step(1);
+            uint32_t u0[4] = {s0.x, s0.y, s0.z, s0.w}, u1[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) swap_halves(u0[i], u1[i]);
+            const v4u q0 = {u0[0], u0[1], u0[2], u0[3]}, q1 = {u1[0], u1[1], u1[2], u1[3]};
+            uint8_t *pp = DX > 0 ? po : po + ostride;   // the pair's lower-x pixel
+            __builtin_nontemporal_store(q0, (CART_GLOBAL v4u *)(sgpr(pp) + pin_v(lo_a)));
+            __builtin_nontemporal_store(q1, (CART_GLOBAL v4u *)(sgpr(pp) + pin_v(lo_b)));
+        } else {
+            const v4u q0 = step(0);
+            __builtin_nontemporal_store(q0, (CART_GLOBAL v4u *)(sgpr(po) + pin_v(lo_o)));
+            const v4u q1 = step(1);
+            __builtin_nontemporal_store(q1, (CART_GLOBAL v4u *)(sgpr(po + ostride) + pin_v(lo_o)));
+        }
         po += 2 * ostride;
     }
-    if (t < w) step(0, po);
+    if (t < w) {
+        const v4u q = step(0);
+        __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)(sgpr(po) + pin_v(lo_o)));
+    }
 }
 
 // prefetch depth of the vertical / diagonal scans in steps (see the note at the loop): 4 at D = 64 (-10 %), 2 elsewhere (flat)
@@ -650,12 +673,18 @@ __global__ __launch_bounds__(64 * kAggWaves, (LPP >= 8 && !HS) ? 6 : 4) void agg
             uint8_t *pos = a.slabs.frame[frame] + uniform((ptrdiff_t)a.dirs[di].path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)y0s * g.w + xs) * g.D);
             const unsigned so_l = (unsigned)pgv * g.cpitch * 4u, so_r = so_l + (unsigned)(WN::D - 16 - d0) * 4u;
             const unsigned so_o = (unsigned)pgv * g.w * g.D + d0;
+            // paired-step stores of the D = 64 consumer (hsplit_consumer): lanes 0-31 store the pair's first step, lanes 32-63 its second, of rows
+            // pg & 7 (first store) and 8 + (pg & 7) (second); offsets count from the pair's lower-x pixel
+            const int rlim = nlines - l0 - 1, r8 = (lane & 31) / LPP;
+            const unsigned xo = ((dx > 0) == (lane >= 32)) ? (unsigned)g.D : 0u;
+            const unsigned so_a = (unsigned)min(r8, rlim) * g.w * g.D + d0 + xo, so_b = (unsigned)min(r8 + 8, rlim) * g.w * g.D + d0 + xo;
             uint32_t *cost = &s_cost[wid >> 1][0];
             if ((wid & 1) == 0) {
                 if (dx > 0) hsplit_producer<LPP, 1>(pls, so_l, prs, so_r, g.w, cost, lane);
                 else hsplit_producer<LPP, -1>(pls, so_l, prs, so_r, g.w, cost, lane);
             } else {
-                hsplit_consumer<LPP>(st, mm, pos, so_o, (ptrdiff_t)dx * g.D, g.w, cost, lane, sel_lo, sel_hi, p1p1, p2p2);
+                if (dx > 0) hsplit_consumer<LPP, 1>(st, mm, pos, so_o, so_a, so_b, g.D, g.w, cost, lane, sel_lo, sel_hi, p1p1, p2p2);
+                else hsplit_consumer<LPP, -1>(st, mm, pos, so_o, so_a, so_b, g.D, g.w, cost, lane, sel_lo, sel_hi, p1p1, p2p2);
             }
             return;
         }
@@ -860,7 +889,7 @@ int agg_residency_cap(int ndirs, int D, int n_frames, bool hsplit) {
 // When the horizontal scans run as producer / consumer wave pairs (hsplit_*).  They pay where the launch waits for its W-step chains --
 // few directions beside them, or few frames -- and cost 1-2 % where the launch has enough other work (profiles/r04_hsplit.txt; aggregate ms per
 // launch, plain / split, means of three alternating runs, 1242x375 unless noted):
-//   D = 64  P = 4:  16 frames 0.598 / 0.548   8 frames 0.482 / 0.339   4 frames 0.292 / 0.248
+//   D = 64  P = 4:  16 frames 0.598 / 0.548   8 frames 0.482 / 0.339   4 frames 0.292 / 0.248   (with the consumer's whole-line stores: 0.503 / 0.305 / 0.244)
 //   D = 256 P = 4:  16 frames 1.210 / 1.230   12 frames 0.984 / 0.962   8 frames 0.796 / 0.651   6 frames 0.701 / 0.553   1920x1080, 4 frames 1.493 / 1.448
 //   D = 128 P = 8:  16 frames 1.453 / 1.456   12 frames 1.147 / 1.166   8 frames 0.782 / 0.785   4 frames 0.473 / 0.451      D = 128 P = 4, 16 frames 0.844 / 0.862
 bool agg_hsplit(const Geometry &g, int ndirs, int n_frames) {
