@@ -891,9 +891,11 @@ int agg_residency_cap(int ndirs, int D, int n_frames, bool hsplit) {
 // launch, plain / split, means of three alternating runs, 1242x375 unless noted):
 //   D = 64  P = 4:  16 frames 0.598 / 0.548   8 frames 0.482 / 0.339   4 frames 0.292 / 0.248   (with the consumer's whole-line stores: 0.503 / 0.305 / 0.244)
 //   D = 256 P = 4:  16 frames 1.210 / 1.230   12 frames 0.984 / 0.962   8 frames 0.796 / 0.651   6 frames 0.701 / 0.553   1920x1080, 4 frames 1.493 / 1.448
+//   D = 64  P = 8:  16 frames 0.957 / 0.861   8 frames 0.686 / 0.504   (pairs/s 9 253 -> 9 870, 7 353 -> 8 856)
 //   D = 128 P = 8:  16 frames 1.453 / 1.456   12 frames 1.147 / 1.166   8 frames 0.782 / 0.785   4 frames 0.473 / 0.451      D = 128 P = 4, 16 frames 0.844 / 0.862
 bool agg_hsplit(const Geometry &g, int ndirs, int n_frames) {
-    return ndirs <= 4 ? (g.D == 64 || n_frames <= 12) : n_frames < 8;
+    if (g.D == 64) return true;   // whatever else the launch holds: a D = 64 pixel is half a line, and only the split consumer stores whole lines
+    return ndirs <= 4 ? n_frames <= 12 : n_frames < 8;
 }
 
 void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {

@@ -72,11 +72,12 @@ def test_sgm_stage_by_stage(torch_cuda, w, h, D, P, md):
     eng.close()
 
 
-@pytest.mark.parametrize("w,h,D,P", [(173, 67, 128, 8), (333, 35, 64, 4), (97, 29, 256, 4), (1242, 375, 64, 4)])
+@pytest.mark.parametrize("w,h,D,P", [(173, 67, 128, 8), (333, 35, 64, 4), (211, 45, 64, 8), (97, 29, 256, 4), (1242, 375, 64, 4)])
 def test_split_horizontal_scans_equal_plain_ones(torch_cuda, w, h, D, P):
     """The aggregation launch runs its horizontal scans as producer / consumer wave pairs when it would otherwise wait for their W-step
     chains (agg_hsplit: few frames, or few directions), and as plain one-wave scans otherwise.  The same frame alone (split) and inside a
-    16-frame batch (plain, for 8 paths; D=64 / 4 paths stays split: both calls are then compared with the oracle only) must leave the
+    16-frame batch (plain, for 8 paths at D >= 128; D=64 always splits -- its consumer is the one that stores whole 128-byte lines, two steps per
+    store pair -- and both calls are then compared with the oracle only) must leave the
     same horizontal slabs, cell for cell, and the oracle's -- on widths that are no multiple of 16 (the producer's tail steps) and heights
     that leave the last workgroup a partial pair and an idle pair (rows cloned, every wave at every barrier)."""
     torch = torch_cuda
