@@ -301,7 +301,8 @@ class StereoPipeline:
         # The outputs are then produced on `self.side`: synchronise (or wait for out["done"]) before reading them on
         # another stream.  Needs engine max_inflight >= 2 * batch.  Measured (ms per 16-pair step, one stream / side stream):
         # D=128 P=8 3.20 / 3.02, D=256 P=4 3.07 / 2.98, D=128 P=4 1.80 / 1.74, 1920x1080 D=256 P=8 (4 pairs) 6.13 / 5.99,
-        # D=64 P=4 1.28 / 1.24.  (Two further layouts -- plane stages gated behind the next batch's aggregation; census and
+        # D=64 P=4 1.28 / 1.24; round 4: D=128 P=8 2.99 / 2.87, D=256 P=4 2.89 / 2.69, D=64 P=4 1.13 / 1.02 (profiles/r04_overlap.txt).
+        # (Two further layouts -- plane stages gated behind the next batch's aggregation; census and
         # post stages on streams of their own -- measured level or slower in round 2 and were removed: DESIGN.md appendix.)
         if overlap == "auto":
             overlap = True

@@ -3,9 +3,9 @@
 #   * host runtime (worker pool, coalescer, frame order, System, retention ring) under ThreadSanitizer and under ASan + UBSan,
 #   * the PNG and JSON readers over mutated / random inputs under ASan + UBSan,
 #   * the oracle's tests under ASan + UBSan, and its OpenMP loops under ThreadSanitizer (clang + libomp + archer).
-# Logs go to profiles/r03_sanitizers/.
+# Logs go to profiles/${ROUND:-r03}_sanitizers/ (ROUND=r04 for this round's host code).
 set -u
-R=$(cd "$(dirname "$0")/../.." && pwd); O=$R/profiles/r03_sanitizers; T=$(mktemp -d); mkdir -p $O
+R=$(cd "$(dirname "$0")/../.." && pwd); O=$R/profiles/${ROUND:-r03}_sanitizers; T=$(mktemp -d); mkdir -p $O
 make -C $R/cart-slam_amd sanitize > $T/build.log 2>&1 || { tail -20 $T/build.log; exit 1; }
 S=$R/cart-slam_amd/build/san
 run() { name=$1; shift; ( "$@" > $T/$name.log 2>&1; echo "exit code $?" >> $T/$name.log ); tail -n 3 $T/$name.log | sed "s/^/[$name] /"; grep -E "^(SUMMARY|WARNING: ThreadSanitizer|ERROR: AddressSanitizer|.*runtime error:)" $T/$name.log | sort | uniq -c > $O/$name.txt; tail -n 4 $T/$name.log >> $O/$name.txt; }
