@@ -304,6 +304,18 @@ def run(args, world, rank, dev_index):
     check_frames = sorted({0, B - 1})
     got = {k: {"disp": last["disparity"][k].cpu().numpy(), "planes": last["planes"][k].cpu().numpy(),
                "params": [int(v) for v in last["params"][k].cpu().numpy()]} for k in check_frames} if rank == 0 else {}
+    # Informational, never `value`: the same block of --steps steps once more WITHOUT the engine's stage events (six hipEventRecord per step on
+    # the launch stream, ~0.02 ms per step: profiles/r04_overlap.txt) -- what the step does uninstrumented.  Same bracket, max over ranks.
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.process_batch(left, right, inputs_ready=resident)
+    torch.cuda.synchronize(); barrier()
+    dt_plain = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_plain], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_plain = float(t.item())
     copy_gbps = None
     if rank == 0:
         # achievable-copy ceiling of THIS box ("quote both fractions"): device-to-device copy of 2 GiB,
@@ -547,6 +559,7 @@ def run(args, world, rank, dev_index):
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(wta_bytes / (wta_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "traffic": measured_traffic("wta"), "traffic_source": "profiles/traffic.json" if measured_traffic("wta") else None,
                                    "alg_bytes_per_launch": wta_bytes, "launch_ms": round(wta_ms, 4)}
+        out["value_without_stage_events"] = round(world * B * args.steps / dt_plain, 2)   # informational: one untimed-by-events block after the timed ones
         if pcie:
             out["pcie_inclusive"] = pcie
             out["value_pcie_inclusive"] = pcie["pairs_per_s"]   # the same step with the pair uploaded and disparity + planes downloaded

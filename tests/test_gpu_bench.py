@@ -39,6 +39,7 @@ def test_single_gpu_line_is_verified_and_complete():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["config"]["distinct_frames_per_batch"] == 4
     assert d["bgr_input"]["disparity_equals_gray_run"] is True and d["value_bgr_input"] > 0   # the 8UC3 input disparity.cu:66-67 is handed
+    assert d["value_without_stage_events"] > 0   # informational block after the timed ones, the engine's stage events off
     pt = d["placement_tuning"]
     assert 0 < pt["launch_pair_ms_kept"] <= pt["launch_pair_ms_first"] and pt["tries"] >= 1
 
