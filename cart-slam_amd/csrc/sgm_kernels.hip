@@ -679,6 +679,9 @@ __global__ __launch_bounds__(64 * kAggWaves, (LPP >= 8 && !HS) ? 6 : 4) void agg
             const unsigned xo = ((dx > 0) == (lane >= 32)) ? (unsigned)g.D : 0u;
             const unsigned so_a = (unsigned)min(r8, rlim) * g.w * g.D + d0 + xo, so_b = (unsigned)min(r8 + 8, rlim) * g.w * g.D + d0 + xo;
             uint32_t *cost = &s_cost[wid >> 1][0];
+            // D = 64: the producer has ~30 % slack per step; below the consumers' priority it stops taking issue slots from the consumer of ANOTHER pair
+            // on its SIMD (aggregate 0.505 -> 0.498 ms at 16 frames, 0.305 -> 0.296 at 8).  At D = 256 the same costs 7 % (0.491 -> 0.524, 6 frames): left at 3.
+            if constexpr (LPP == 4) { if ((wid & 1) == 0) __builtin_amdgcn_s_setprio(1); }
             if ((wid & 1) == 0) {
                 if (dx > 0) hsplit_producer<LPP, 1>(pls, so_l, prs, so_r, g.w, cost, lane);
                 else hsplit_producer<LPP, -1>(pls, so_l, prs, so_r, g.w, cost, lane);
