@@ -33,6 +33,7 @@ CFG[d64p8]="--disparities 64 --paths 8"
 CFG[d64p8b8]="--disparities 64 --paths 8 --batch 8"
 CFG[c1b32]="--disparities 64 --paths 4 --batch 32 --chunk 32"
 CFG[c1b24]="--disparities 64 --paths 4 --batch 24 --chunk 24"
+CFG[d128p4b8]="--disparities 128 --paths 4 --batch 8"
 CFG[ref32]="--disparities 256 --paths 4 --batch 32 --chunk 32"
 for r in $(seq $ROUNDS); do
   for c in ${CONFIGS:-ref c3 c2f d256p8}; do
