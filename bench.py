@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--no-bgr", action="store_true", help="skip the informational 3-channel-input leg (`value_bgr_input`: what ImageDisparityModule::runInternal is handed, disparity.cu:66-67)")
     ap.add_argument("--latency", action="store_true", help="also time ONE resident pair, host-synchronous (informational `single_pair_latency`; off by default so that "
                     "every aggregation / WTA launch of the default command is a full batch and rocprofv3 --stats averages agree with `roofline.launch_ms`)")
-    ap.add_argument("--placement-tries", type=int, default=32, help="physical placements of the slab workspace the engine may try at set-up (1 = keep the first)")
+    ap.add_argument("--placement-tries", type=int, default=64, help="physical placements of the slab workspace the engine may try at set-up (1 = keep the first)")
     ap.add_argument("--no-overlap", action="store_true", help="run the plane stages on the main stream (no two-stream pipelining of consecutive batches)")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream pipelining (the default)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed block of --steps steps is run this many times; `value` is the median block, `spread` the fastest / slowest")
