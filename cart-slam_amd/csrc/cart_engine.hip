@@ -1139,7 +1139,7 @@ struct cart_superpixels {
     uint16_t *labels[2] = {nullptr, nullptr};  // tight [h][w]; labels[cur] is the state
     int cur = 0;
     uint32_t *ycc = nullptr;
-    long long *stats = nullptr, *delta = nullptr;  // [kSpStatRows][kSpMaxLabels]-capacity
+    long long *stats = nullptr;  // [kSpStatRows][ld] statistics followed by [kSpStatRows][ld] of per-sweep delta (capacity 2 x kSpStatRows x kSpMaxLabels)
     double *costs = nullptr;
     int *max_seen = nullptr;
     std::mutex mu;               // serialises calls (superpixels.cu:97-99)
@@ -1194,8 +1194,7 @@ int cart_superpixels_create(cart_engine *e, const cart_superpixel_params *params
     bool ok = hipMalloc(reinterpret_cast<void **>(&sp->labels[0]), g.npx * 2) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&sp->labels[1]), g.npx * 2) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&sp->ycc), g.npx * 4) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&sp->stats), stat_elems * 8) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&sp->delta), stat_elems * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&sp->stats), 2 * stat_elems * 8) == hipSuccess &&   // statistics, then their per-sweep delta (one memset per call)
               hipMalloc(reinterpret_cast<void **>(&sp->costs), (size_t)kSpChannels * kSpMaxLabels * 8) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&sp->max_seen), sizeof(int)) == hipSuccess &&
               hipEventCreateWithFlags(&sp->done, hipEventDisableTiming) == hipSuccess;
@@ -1215,7 +1214,7 @@ void cart_superpixels_destroy(cart_superpixels *sp) {
     if (!sp) return;
     if (sp->engine) (void)hipSetDevice(sp->engine->params.device_id);
     (void)hipDeviceSynchronize();
-    void *bufs[] = {sp->labels[0], sp->labels[1], sp->ycc, sp->stats, sp->delta, sp->costs, sp->max_seen};
+    void *bufs[] = {sp->labels[0], sp->labels[1], sp->ycc, sp->stats, sp->costs, sp->max_seen};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (sp->done) (void)hipEventDestroy(sp->done);
@@ -1284,20 +1283,21 @@ int cart_superpixels_relax(cart_superpixels *sp, const uint8_t *image, size_t im
     SpRelaxArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ycc = sp->ycc; a.deriv = p.disparity_weight > 0 ? deriv2 : nullptr; a.deriv_step = deriv2_step;
-    a.stats = sp->stats; a.costs = sp->costs; a.delta = sp->delta; a.ld = ld; a.w = g.w; a.h = g.h;
+    a.stats = sp->stats; a.costs = sp->costs; a.delta = sp->stats + (size_t)kSpStatRows * ld; a.ld = ld; a.w = g.w; a.h = g.h;
     a.ch_mask = (p.compactness_weight > 0 ? 0x03u : 0u) | (p.disparity_weight > 0 ? 0x0cu : 0u) | (p.image_weight > 0 ? 0x70u : 0u);
     a.direct = p.direct_clique_cost; a.diagonal = p.diagonal_clique_cost; a.w_comp = p.compactness_weight;
     a.prog = p.progressive_compactness_cost; a.w_img = p.image_weight; a.w_disp = p.disparity_weight;
-    launch_sp_ycrcb(image, image_step, channels, sp->ycc, g.w, g.h, stream);
-    HIP_TRY(hipMemsetAsync(sp->stats, 0, (size_t)kSpStatRows * ld * 8, stream));
-    HIP_TRY(hipMemsetAsync(sp->delta, 0, (size_t)kSpStatRows * ld * 8, stream));
-    a.cur = sp->labels[sp->cur]; a.next = sp->labels[sp->cur ^ 1];
-    launch_sp_stats(a, stream);
-    launch_sp_fold(sp->stats, sp->delta, sp->costs, ld, a.ch_mask, stream);
+    if (iterations > 0) {   // the colour planes and the label statistics only serve the sweeps; every call rebuilds them from the image and the labels
+        launch_sp_ycrcb(image, image_step, channels, sp->ycc, g.w, g.h, stream);
+        HIP_TRY(hipMemsetAsync(sp->stats, 0, 2 * (size_t)kSpStatRows * ld * 8, stream));
+        a.cur = sp->labels[sp->cur]; a.next = sp->labels[sp->cur ^ 1];
+        launch_sp_stats(a, stream);
+        launch_sp_fold(a.stats, a.delta, sp->costs, ld, a.ch_mask, stream);
+    }
     for (int it = 0; it < iterations; ++it) {
         a.cur = sp->labels[sp->cur]; a.next = sp->labels[sp->cur ^ 1];
         launch_sp_relax(a, stream);
-        launch_sp_fold(sp->stats, sp->delta, sp->costs, ld, a.ch_mask, stream);
+        if (it + 1 < iterations) launch_sp_fold(a.stats, a.delta, sp->costs, ld, a.ch_mask, stream);   // the last sweep's delta has no reader
         sp->cur ^= 1;
     }
     if (labels_out) launch_sp_copy(sp->labels[sp->cur], (size_t)g.w * 2, labels_out, labels_out_step, g.w, g.h, nullptr, stream);

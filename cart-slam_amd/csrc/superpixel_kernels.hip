@@ -10,12 +10,17 @@
 // MI355X design: the reference compacts border pixels into a global list and reads its length back to the host in
 // every iteration (one device->host round trip per iteration) and keeps per-label statistics behind device-side
 // virtual calls.  Here one iteration is two launches and no host round trip:
-//   sp_relax_kernel   one 32x16 tile per workgroup; labels + halo in LDS; border pixels are compacted into an LDS
-//                     list so that all 256 lanes work on border pixels; every border pixel evaluates its candidate
+//   sp_relax_kernel   one 32x16 tile per workgroup; labels + halo in LDS; the tile's ~20 distinct labels get slots in an
+//                     LDS table that holds their statistics rows and feature costs (fetched once per workgroup); border
+//                     pixels are compacted into an LDS list, ordered by their number of candidate labels, so that all
+//                     256 lanes work on border pixels with like trip counts; every border pixel evaluates its candidate
 //                     labels against the label statistics of the iteration start (Jacobi, oracle S13), writes the
 //                     next label image and accumulates the statistics DELTA of its own move with 64-bit integer
 //                     atomics (sums of integers: exact, order independent);
-//   sp_fold_kernel    statistics += delta, delta = 0, per-label feature costs refreshed (one thread per label).
+//   sp_fold_kernel    statistics += delta, delta = 0, per-label feature costs refreshed (one thread per label; not after
+//                     the last sweep of a call: the next call rebuilds the statistics from the image and the labels).
+//   sp_stats_kernel   the statistics of a call's first sweep: per tile into the same kind of LDS table, one global
+//                     atomic per label and row.
 // Statistics are structure-of-arrays [row][label] so that a wave's candidate look-ups hit the same few cache lines.
 // All cost arithmetic is IEEE double in the oracle's operation order, no FMA contraction, log() = the S13 sequence.
 #include "engine_internal.h"
@@ -106,38 +111,84 @@ __global__ __launch_bounds__(256) void sp_ycrcb_kernel(const uint8_t *img, size_
 }
 
 // ------------------------------------------------------------------ statistics of the current labelling
-// One thread walks a 16-pixel strip of a row and flushes its partial sums whenever the label changes (superpixels
-// are ~block_size wide, so ~2 flushes per strip instead of 16 x 15 atomics).
+// One workgroup per 32x16 tile: the tile's ~20 labels get slots in an LDS table (as in sp_relax_kernel below), every thread adds its two pixels to the
+// slot's 15 accumulators with LDS atomics, and the tile leaves ONE global atomic per label and row (~300 per tile instead of ~900 from per-strip flushes:
+// 35 -> 15 us per frame at 1242x375).  Sums of integers: exact and order independent.  A tile with more labels than slots adds straight to global memory.
+constexpr int kSpSlots = 64;
+constexpr unsigned kSpEmpty = 0xFFFFFFFFu;
+__device__ __forceinline__ unsigned sp_hash(unsigned L) { return (L ^ (L >> 6) ^ (L >> 11)) & (kSpSlots - 1); }
+// inserts L (first of a run of equal labels) into the open-addressing table; false when the table is full
+__device__ __forceinline__ bool sp_table_insert(unsigned *hkey, unsigned L) {
+    unsigned h = sp_hash(L);
+    for (int probes = 0; probes < kSpSlots; ++probes) {
+        const unsigned old = atomicCAS(&hkey[h], kSpEmpty, L);
+        if (old == kSpEmpty || old == L) return true;
+        h = (h + 1) & (kSpSlots - 1);
+    }
+    return false;
+}
+__device__ __forceinline__ unsigned sp_table_find(const unsigned *hkey, unsigned L) {   // L is in the table
+    unsigned h = sp_hash(L);
+    while (hkey[h] != L) h = (h + 1) & (kSpSlots - 1);
+    return h;
+}
+
 __global__ __launch_bounds__(256) void sp_stats_kernel(SpRelaxArgs a) {
-    const int strips = (a.w + 15) / 16;
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= strips * a.h) return;
-    const int y = id / strips, xs = (id % strips) * 16, xe = min(xs + 16, a.w);
-    long long acc[kSpStatRows];
-#pragma unroll
-    for (int r = 0; r < kSpStatRows; ++r) acc[r] = 0;
-    int cur = a.cur[(size_t)y * a.w + xs];
-    for (int x = xs; x <= xe; ++x) {
-        const int L = x < xe ? a.cur[(size_t)y * a.w + x] : -1;
-        if (L != cur) {
-            atomic_add_i64(&a.stats[cur], acc[0]);
+    __shared__ uint16_t tile[kTileH][kTileW];
+    __shared__ unsigned hkey[kSpSlots];
+    __shared__ unsigned long long acc[kSpStatRows][kSpSlots];
+    __shared__ int overflow;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    if (tid == 0) overflow = 0;
+    if (tid < kSpSlots) hkey[tid] = kSpEmpty;
+    for (int i = tid; i < kSpStatRows * kSpSlots; i += 256) (&acc[0][0])[i] = 0ull;
+    for (int i = tid; i < kTileW * kTileH; i += 256) {
+        const int lx = i % kTileW, ly = i / kTileW;
+        const int x = x0 + lx, y = y0 + ly;
+        tile[ly][lx] = (x < a.w && y < a.h) ? a.cur[(size_t)y * a.w + x] : kOob;
+    }
+    __syncthreads();
+    for (int i = tid; i < kTileW * kTileH; i += 256) {
+        const int lx = i % kTileW, ly = i / kTileW;
+        const unsigned L = tile[ly][lx];
+        if (L == kOob || (lx > 0 && tile[ly][lx - 1] == L)) continue;
+        if (!sp_table_insert(hkey, L)) overflow = 1;
+    }
+    __syncthreads();
+    const bool direct = overflow != 0;
+    for (int i = tid; i < kTileW * kTileH; i += 256) {
+        const int lx = i % kTileW, ly = i / kTileW;
+        const unsigned L = tile[ly][lx];
+        if (L == kOob) continue;
+        long long v[kSpChannels];
+        pixel_values(a, x0 + lx, y0 + ly, v);
+        if (direct) {
+            atomic_add_i64(&a.stats[L], 1);
 #pragma unroll
             for (int ch = 0; ch < kSpChannels; ++ch)
                 if ((a.ch_mask >> ch) & 1u) {
-                    atomic_add_i64(&a.stats[(size_t)(1 + ch) * a.ld + cur], acc[1 + ch]);
-                    atomic_add_i64(&a.stats[(size_t)(8 + ch) * a.ld + cur], acc[8 + ch]);
+                    atomic_add_i64(&a.stats[(size_t)(1 + ch) * a.ld + L], v[ch]);
+                    atomic_add_i64(&a.stats[(size_t)(8 + ch) * a.ld + L], v[ch] * v[ch]);
                 }
+        } else {
+            const unsigned sl = sp_table_find(hkey, L);
+            atomicAdd(&acc[0][sl], 1ull);
 #pragma unroll
-            for (int r = 0; r < kSpStatRows; ++r) acc[r] = 0;
-            cur = L;
+            for (int ch = 0; ch < kSpChannels; ++ch)
+                if ((a.ch_mask >> ch) & 1u) {
+                    atomicAdd(&acc[1 + ch][sl], (unsigned long long)v[ch]);
+                    atomicAdd(&acc[8 + ch][sl], (unsigned long long)(v[ch] * v[ch]));
+                }
         }
-        if (x < xe) {
-            long long v[kSpChannels];
-            pixel_values(a, x, y, v);
-            acc[0] += 1;
-#pragma unroll
-            for (int ch = 0; ch < kSpChannels; ++ch) { acc[1 + ch] += v[ch]; acc[8 + ch] += v[ch] * v[ch]; }
-        }
+    }
+    if (direct) return;
+    __syncthreads();
+    for (int i = tid; i < kSpStatRows * kSpSlots; i += 256) {
+        const int sl = i & (kSpSlots - 1), row = i / kSpSlots;
+        const unsigned L = hkey[sl];
+        const unsigned long long s = acc[row][sl];
+        if (L != kSpEmpty && s != 0ull) atomicAdd(reinterpret_cast<unsigned long long *>(&a.stats[(size_t)row * a.ld + L]), s);
     }
 }
 
@@ -159,20 +210,155 @@ __global__ __launch_bounds__(256) void sp_fold_kernel(long long *stats, long lon
 }
 
 // ------------------------------------------------------------------ one relaxation sweep (contourrelaxation.cu:248-322)
+// Where a border pixel's candidate labels get their statistics from.  A tile and its halo hold ~20 distinct labels; their 15 statistics rows and 7 feature
+// costs are fetched ONCE per workgroup into an LDS table (SpLdsAcc: the per-pixel loops then address labels by their table slot), instead of once per pixel,
+// candidate and neighbour label from global memory, one dependent load after the other (the sweep is bound by exactly those latencies: 43 us for 6 us worth of
+// arithmetic, profiles/r04_superpixels.txt).  A tile with more than kSpSlots distinct labels takes the global-memory path (SpGlobalAcc: ids are the labels).
+struct SpGlobalAcc {
+    const long long *stats; const double *costs; int ld;
+    __device__ __forceinline__ long long stat(int row, int id) const { return stats[(size_t)row * ld + id]; }
+    __device__ __forceinline__ double cost(int ch, int id) const { return costs[(size_t)ch * ld + id]; }
+    __device__ __forceinline__ int label(int id) const { return id; }
+};
+struct SpLdsAcc {
+    const long long (*st)[kSpSlots]; const double (*co)[kSpSlots]; const unsigned *key;
+    __device__ __forceinline__ long long stat(int row, int id) const { return st[row][id]; }
+    __device__ __forceinline__ double cost(int ch, int id) const { return co[ch][id]; }
+    __device__ __forceinline__ int label(int id) const { return (int)key[id]; }
+};
+
+// The border pixels of a tile: candidates, costs, choice, statistics delta.  `ids` = the tile + halo as label ids of `acc` (kOob outside the image).
+template <class Acc>
+__device__ __forceinline__ void sp_relax_border(const SpRelaxArgs &a, const Acc &acc, const uint16_t (*ids)[kTileW + 2], const uint16_t *list, int n_border,
+                                                uint16_t (*cand)[256], int x0, int y0, int tid) {
+    const int ld = a.ld;
+    for (int i = tid; i < n_border; i += 256) {
+        const int lx = list[i] & 0xff, ly = list[i] >> 8;
+        const int x = x0 + lx, y = y0 + ly;
+        int nb[9];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) nb[(dx + 1) + (dy + 1) * 3] = ids[ly + 1 + dy][lx + 1 + dx];
+        // unique neighbour labels, dx outer / dy inner like getNeighbourLabels (contourrelaxation.cu:79-108)
+        int nN = 0;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int L = nb[(dx + 1) + (dy + 1) * 3];
+                if (L != kOob) {
+                    bool found = false;
+                    for (int k = 0; k < nN; ++k) found |= cand[k][tid] == L;
+                    if (!found) cand[nN++][tid] = (uint16_t)L;
+                }
+            }
+        const int O = nb[4];
+        long long v[kSpChannels];
+        pixel_values(a, x, y, v);
+        // O after losing this pixel (the same for every candidate != O)
+        const long long on_less = acc.stat(0, O) - 1;
+        double oc[kSpChannels];
+#pragma unroll
+        for (int ch = 0; ch < kSpChannels; ++ch)
+            oc[ch] = ((a.ch_mask >> ch) & 1u) ? channel_cost(ch, on_less, acc.stat(1 + ch, O) - v[ch], acc.stat(8 + ch, O) - v[ch] * v[ch]) : 0.0;
+        int best = O;
+        double min_cost = 0x1.fffffffffffffp+1023;  // DBL_MAX
+        for (int ci = 0; ci < nN; ++ci) {
+            const int P = cand[ci][tid];
+#define CART_DIFF(k) ((nb[k] != kOob) & (nb[k] != P))
+            const int nd = CART_DIFF(3) + CART_DIFF(5) + CART_DIFF(1) + CART_DIFF(7);
+            const int ng = CART_DIFF(0) + CART_DIFF(6) + CART_DIFF(2) + CART_DIFF(8);
+#undef CART_DIFF
+            double cost = nd * a.direct + ng * a.diagonal;
+            const bool move = P != O;
+            long long pn_more = 0;
+            double pc[kSpChannels];
+            if (move) {
+                pn_more = acc.stat(0, P) + 1;
+#pragma unroll
+                for (int ch = 0; ch < kSpChannels; ++ch)
+                    pc[ch] = ((a.ch_mask >> ch) & 1u) ? channel_cost(ch, pn_more, acc.stat(1 + ch, P) + v[ch], acc.stat(8 + ch, P) + v[ch] * v[ch]) : 0.0;
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < kSpChannels; ++ch) pc[ch] = 0.0;
+            }
+            double fc = 0, fd = 0, fi = 0;
+            for (int j = 0; j < nN; ++j) {
+                const int L = cand[j][tid];
+                long long n;
+                double k[kSpChannels];
+                if (move && L == O) {
+                    n = on_less;
+#pragma unroll
+                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = oc[ch];
+                } else if (move && L == P) {
+                    n = pn_more;
+#pragma unroll
+                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = pc[ch];
+                } else {
+                    n = acc.stat(0, L);
+#pragma unroll
+                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = acc.cost(ch, L);
+                }
+                if (n == 0) continue;
+                fc += k[0] + k[1];
+                fd += k[2]; fd += k[3];
+                fi += k[4]; fi += k[5]; fi += k[6];
+            }
+            if (a.w_comp > 0) {
+                if (a.prog > 0.0) fc *= 1.0 + a.prog * ((double)a.h - (double)y) / (double)a.h;
+                cost += a.w_comp * fc;
+            }
+            if (a.w_disp > 0) cost += a.w_disp * (fd / 2.0);
+            if (a.w_img > 0) cost += a.w_img * (fi / 3.0);
+            if (cost < min_cost) { min_cost = cost; best = P; }
+        }
+        const int lbest = acc.label(best), lO = acc.label(O);
+        a.next[(size_t)y * a.w + x] = (uint16_t)lbest;
+        if (best != O) {  // updateLabels (contourrelaxation.cu:296-322), as a delta folded in by sp_fold_kernel
+            atomic_add_i64(&a.delta[lO], -1);
+            atomic_add_i64(&a.delta[lbest], 1);
+#pragma unroll
+            for (int ch = 0; ch < kSpChannels; ++ch)
+                if ((a.ch_mask >> ch) & 1u) {
+                    atomic_add_i64(&a.delta[(size_t)(1 + ch) * ld + lO], -v[ch]);
+                    atomic_add_i64(&a.delta[(size_t)(8 + ch) * ld + lO], -v[ch] * v[ch]);
+                    atomic_add_i64(&a.delta[(size_t)(1 + ch) * ld + lbest], v[ch]);
+                    atomic_add_i64(&a.delta[(size_t)(8 + ch) * ld + lbest], v[ch] * v[ch]);
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sp_relax_kernel(SpRelaxArgs a) {
-    __shared__ uint16_t tile[kTileH + 2][kTileW + 2];
-    __shared__ uint16_t list[kTileW * kTileH];
+    __shared__ uint16_t tile[kTileH + 2][kTileW + 2];    // labels
+    __shared__ uint16_t tslot[kTileH + 2][kTileW + 2];   // the same entries as slots of the label table
+    __shared__ uint16_t list[kTileW * kTileH], sorted[kTileW * kTileH];
     __shared__ uint16_t cand[9][256];
-    __shared__ int count;
+    __shared__ int bucket[10];
+    __shared__ unsigned hkey[kSpSlots];
+    __shared__ long long c_stats[kSpStatRows][kSpSlots];
+    __shared__ double c_costs[kSpChannels][kSpSlots];
+    __shared__ int count, overflow;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
-    if (tid == 0) count = 0;
+    if (tid == 0) { count = 0; overflow = 0; }
+    if (tid < kSpSlots) hkey[tid] = kSpEmpty;
+    if (tid < 10) bucket[tid] = 0;
     for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
         const int ly = i / (kTileW + 2), lx = i % (kTileW + 2);
         const int x = x0 + lx - 1, y = y0 + ly - 1;
         tile[ly][lx] = (x >= 0 && x < a.w && y >= 0 && y < a.h) ? a.cur[(size_t)y * a.w + x] : kOob;
     }
     __syncthreads();
+    // label table: open addressing, one insertion per run of equal labels along a row (~50 insertions instead of 612)
+    for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
+        const int ly = i / (kTileW + 2), lx = i % (kTileW + 2);
+        const unsigned L = tile[ly][lx];
+        if (L == kOob || (lx > 0 && tile[ly][lx - 1] == L)) continue;
+        if (!sp_table_insert(hkey, L)) overflow = 1;
+    }
     // pixels whose in-image neighbourhood holds a single label keep it (they would have one candidate only)
 #pragma unroll
     for (int k = 0; k < kTileW * kTileH / 256; ++k) {
@@ -194,107 +380,62 @@ __global__ __launch_bounds__(256) void sp_relax_kernel(SpRelaxArgs a) {
     }
     __syncthreads();
     const int n_border = count;
-    const int ld = a.ld;
-    for (int i = tid; i < n_border; i += 256) {
-        const int lx = list[i] & 0xff, ly = list[i] >> 8;
-        const int x = x0 + lx, y = y0 + ly;
-        int nb[9];
+    if (n_border == 0) return;
+    // The border pixels ordered by their number of candidate labels: a wave walks its candidate loops as often as its pixel with the MOST candidates needs
+    // (each walk ~2 500 issue cycles of double-precision divisions and logarithms), and in list order nearly every wave holds a 3- or 4-label pixel among
+    // its 2-label ones.  Counting sort over the nine possible counts; the order inside a count does not matter (every pixel reads the sweep's start state).
+    {
+        int nn[kTileW * kTileH / 256];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int k = 0; k < kTileW * kTileH / 256; ++k) {
+            const int i = tid + 256 * k;
+            nn[k] = 0;
+            if (i < n_border) {
+                const int lx = list[i] & 0xff, ly = list[i] >> 8;
+                uint16_t nb[9];
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) nb[(dx + 1) + (dy + 1) * 3] = tile[ly + 1 + dy][lx + 1 + dx];
-        // unique neighbour labels, dx outer / dy inner like getNeighbourLabels (contourrelaxation.cu:79-108)
-        int nN = 0;
+                for (int q = 0; q < 9; ++q) nb[q] = tile[ly + q / 3][lx + q % 3];
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
+                for (int q = 0; q < 9; ++q) {
+                    bool fresh = nb[q] != kOob;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int L = nb[(dx + 1) + (dy + 1) * 3];
-                if (L != kOob) {
-                    bool found = false;
-                    for (int k = 0; k < nN; ++k) found |= cand[k][tid] == L;
-                    if (!found) cand[nN++][tid] = (uint16_t)L;
+                    for (int r = 0; r < q; ++r) fresh &= nb[r] != nb[q];
+                    nn[k] += fresh;
                 }
+                atomicAdd(&bucket[nn[k]], 1);
             }
-        const int O = nb[4];
-        long long v[kSpChannels];
-        pixel_values(a, x, y, v);
-        // O after losing this pixel (the same for every candidate != O)
-        const long long on_less = a.stats[O] - 1;
-        double oc[kSpChannels];
-#pragma unroll
-        for (int ch = 0; ch < kSpChannels; ++ch)
-            oc[ch] = ((a.ch_mask >> ch) & 1u)
-                         ? channel_cost(ch, on_less, a.stats[(size_t)(1 + ch) * ld + O] - v[ch], a.stats[(size_t)(8 + ch) * ld + O] - v[ch] * v[ch])
-                         : 0.0;
-        int best = O;
-        double min_cost = 0x1.fffffffffffffp+1023;  // DBL_MAX
-        for (int ci = 0; ci < nN; ++ci) {
-            const int P = cand[ci][tid];
-#define CART_DIFF(k) ((nb[k] != kOob) & (nb[k] != P))
-            const int nd = CART_DIFF(3) + CART_DIFF(5) + CART_DIFF(1) + CART_DIFF(7);
-            const int ng = CART_DIFF(0) + CART_DIFF(6) + CART_DIFF(2) + CART_DIFF(8);
-#undef CART_DIFF
-            double cost = nd * a.direct + ng * a.diagonal;
-            const bool move = P != O;
-            long long pn_more = 0;
-            double pc[kSpChannels];
-            if (move) {
-                pn_more = a.stats[P] + 1;
-#pragma unroll
-                for (int ch = 0; ch < kSpChannels; ++ch)
-                    pc[ch] = ((a.ch_mask >> ch) & 1u)
-                                 ? channel_cost(ch, pn_more, a.stats[(size_t)(1 + ch) * ld + P] + v[ch], a.stats[(size_t)(8 + ch) * ld + P] + v[ch] * v[ch])
-                                 : 0.0;
-            } else {
-#pragma unroll
-                for (int ch = 0; ch < kSpChannels; ++ch) pc[ch] = 0.0;
-            }
-            double fc = 0, fd = 0, fi = 0;
-            for (int j = 0; j < nN; ++j) {
-                const int L = cand[j][tid];
-                long long n;
-                double k[kSpChannels];
-                if (move && L == O) {
-                    n = on_less;
-#pragma unroll
-                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = oc[ch];
-                } else if (move && L == P) {
-                    n = pn_more;
-#pragma unroll
-                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = pc[ch];
-                } else {
-                    n = a.stats[L];
-#pragma unroll
-                    for (int ch = 0; ch < kSpChannels; ++ch) k[ch] = a.costs[(size_t)ch * ld + L];
-                }
-                if (n == 0) continue;
-                fc += k[0] + k[1];
-                fd += k[2]; fd += k[3];
-                fi += k[4]; fi += k[5]; fi += k[6];
-            }
-            if (a.w_comp > 0) {
-                if (a.prog > 0.0) fc *= 1.0 + a.prog * ((double)a.h - (double)y) / (double)a.h;
-                cost += a.w_comp * fc;
-            }
-            if (a.w_disp > 0) cost += a.w_disp * (fd / 2.0);
-            if (a.w_img > 0) cost += a.w_img * (fi / 3.0);
-            if (cost < min_cost) { min_cost = cost; best = P; }
         }
-        a.next[(size_t)y * a.w + x] = (uint16_t)best;
-        if (best != O) {  // updateLabels (contourrelaxation.cu:296-322), as a delta folded in by sp_fold_kernel
-            atomic_add_i64(&a.delta[O], -1);
-            atomic_add_i64(&a.delta[best], 1);
-#pragma unroll
-            for (int ch = 0; ch < kSpChannels; ++ch)
-                if ((a.ch_mask >> ch) & 1u) {
-                    atomic_add_i64(&a.delta[(size_t)(1 + ch) * ld + O], -v[ch]);
-                    atomic_add_i64(&a.delta[(size_t)(8 + ch) * ld + O], -v[ch] * v[ch]);
-                    atomic_add_i64(&a.delta[(size_t)(1 + ch) * ld + best], v[ch]);
-                    atomic_add_i64(&a.delta[(size_t)(8 + ch) * ld + best], v[ch] * v[ch]);
-                }
+        __syncthreads();
+        if (tid == 0) {
+            int base = 0;
+            for (int q = 0; q < 10; ++q) { const int c = bucket[q]; bucket[q] = base; base += c; }
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kTileW * kTileH / 256; ++k) {
+            const int i = tid + 256 * k;
+            if (i < n_border) sorted[atomicAdd(&bucket[nn[k]], 1)] = list[i];
+        }
+        __syncthreads();
     }
+    if (overflow) {   // more distinct labels than the table holds: every look-up from global memory
+        sp_relax_border(a, SpGlobalAcc{a.stats, a.costs, a.ld}, tile, sorted, n_border, cand, x0, y0, tid);
+        return;
+    }
+    for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
+        const int ly = i / (kTileW + 2), lx = i % (kTileW + 2);
+        const unsigned L = tile[ly][lx];
+        tslot[ly][lx] = (uint16_t)(L != kOob ? sp_table_find(hkey, L) : (unsigned)kOob);
+    }
+    for (int i = tid; i < (kSpStatRows + kSpChannels) * kSpSlots; i += 256) {
+        const int slot = i & (kSpSlots - 1), row = i / kSpSlots;
+        const unsigned L = hkey[slot];
+        if (L == kSpEmpty) continue;
+        if (row < kSpStatRows) c_stats[row][slot] = a.stats[(size_t)row * a.ld + L];
+        else c_costs[row - kSpStatRows][slot] = a.costs[(size_t)(row - kSpStatRows) * a.ld + L];
+    }
+    __syncthreads();
+    sp_relax_border(a, SpLdsAcc{c_stats, c_costs, hkey}, tslot, sorted, n_border, cand, x0, y0, tid);
 }
 
 // ------------------------------------------------------------------ label image copies (tight <-> pitched) + range check
@@ -375,8 +516,7 @@ void launch_sp_ycrcb(const uint8_t *img, size_t step, int channels, uint32_t *yc
     hipLaunchKernelGGL(sp_ycrcb_kernel, px_grid(w, h), dim3(256), 0, s, img, step, channels, ycc, w, h);
 }
 void launch_sp_stats(const SpRelaxArgs &a, hipStream_t s) {
-    const int threads = ((a.w + 15) / 16) * a.h;
-    hipLaunchKernelGGL(sp_stats_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sp_stats_kernel, dim3((a.w + kTileW - 1) / kTileW, (a.h + kTileH - 1) / kTileH), dim3(256), 0, s, a);
 }
 void launch_sp_fold(long long *stats, long long *delta, double *costs, int ld, unsigned ch_mask, hipStream_t s) {
     hipLaunchKernelGGL(sp_fold_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, stats, delta, costs, ld, ch_mask);
