@@ -62,7 +62,8 @@ def make_sp(eng, bs, kw, block_h=None):
                        disparity_weight=kw.get("disparity", 1.0))
 
 
-@pytest.mark.parametrize("w,h,bs,case", [(96, 64, 8, 0), (131, 77, 12, 1), (64, 16, 5, 2), (200, 45, 10, 3), (77, 130, 7, 4), (90, 70, 9, 5)])
+@pytest.mark.parametrize("w,h,bs,case", [(96, 64, 8, 0), (131, 77, 12, 1), (64, 16, 5, 2), (200, 45, 10, 3), (77, 130, 7, 4), (90, 70, 9, 5),
+                                          (70, 41, 3, 1), (66, 50, 2, 0), (100, 37, 4, 2)])   # blocks of 2-4 pixels: more labels in a tile than its LDS table holds
 def test_relax_matches_oracle(torch_cuda, w, h, bs, case):
     torch = torch_cuda
     kw = PARAM_SETS[case]
