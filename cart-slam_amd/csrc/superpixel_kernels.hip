@@ -192,21 +192,26 @@ __global__ __launch_bounds__(256) void sp_stats_kernel(SpRelaxArgs a) {
     }
 }
 
-// statistics += delta; delta = 0; per-label feature costs (gaussian.cu:34-46, compactness.cu:30-37)
+// statistics += delta; delta = 0; per-label feature costs (gaussian.cu:34-46, compactness.cu:30-37).  Eight lanes per label: lanes 0..6 take one channel each
+// (its two statistics rows and its cost: three divisions and a logarithm series at most -- one thread per label walked seven of them in sequence, 7.4 us per
+// launch between every two sweeps), lane 7 the pixel count, which it hands to the others before anything is written.
 __global__ __launch_bounds__(256) void sp_fold_kernel(long long *stats, long long *delta, double *costs, int ld, unsigned ch_mask) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= ld) return;
-    long long s[kSpStatRows];
-#pragma unroll
-    for (int r = 0; r < kSpStatRows; ++r) {
-        const size_t i = (size_t)r * ld + l;
-        s[r] = stats[i] + delta[i];
-        stats[i] = s[r];
-        delta[i] = 0;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int l = t >> 3, p = t & 7;
+    const bool live = l < ld;
+    long long n = 0;
+    if (live && p == 7) {
+        n = stats[l] + delta[l];
+        stats[l] = n;
+        delta[l] = 0;
     }
-#pragma unroll
-    for (int ch = 0; ch < kSpChannels; ++ch)
-        costs[(size_t)ch * ld + l] = ((ch_mask >> ch) & 1u) ? channel_cost(ch, s[0], s[1 + ch], s[8 + ch]) : 0.0;
+    n = __shfl(n, (int)(threadIdx.x & 63u) | 7);   // every lane of the wave takes part (ld need not fill the last wave)
+    if (!live || p == 7) return;
+    const size_t is = (size_t)(1 + p) * ld + l, iq = (size_t)(8 + p) * ld + l;
+    const long long s = stats[is] + delta[is], q = stats[iq] + delta[iq];
+    stats[is] = s; stats[iq] = q;
+    delta[is] = 0; delta[iq] = 0;
+    costs[(size_t)p * ld + l] = ((ch_mask >> p) & 1u) ? channel_cost(p, n, s, q) : 0.0;
 }
 
 // ------------------------------------------------------------------ one relaxation sweep (contourrelaxation.cu:248-322)
@@ -519,7 +524,7 @@ void launch_sp_stats(const SpRelaxArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(sp_stats_kernel, dim3((a.w + kTileW - 1) / kTileW, (a.h + kTileH - 1) / kTileH), dim3(256), 0, s, a);
 }
 void launch_sp_fold(long long *stats, long long *delta, double *costs, int ld, unsigned ch_mask, hipStream_t s) {
-    hipLaunchKernelGGL(sp_fold_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, stats, delta, costs, ld, ch_mask);
+    hipLaunchKernelGGL(sp_fold_kernel, dim3((ld * 8 + 255) / 256), dim3(256), 0, s, stats, delta, costs, ld, ch_mask);
 }
 void launch_sp_relax(const SpRelaxArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(sp_relax_kernel, dim3((a.w + kTileW - 1) / kTileW, (a.h + kTileH - 1) / kTileH), dim3(256), 0, s, a);
