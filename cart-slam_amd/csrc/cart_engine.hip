@@ -559,11 +559,12 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
         // at most this many bytes beyond the workspace at any time (0 = two units' worth); SIZE_MAX = whatever leaves 4 GiB free
         const size_t cap = max_extra_bytes ? max_extra_bytes : 2 * unit_bytes;
         for (int t = 1; t < max_tries && !mine.empty(); ++t) {
-            // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 11.5 % under the slowest pair seen has
-            // the aggregation in its fast mode and the WTA not in its slow one -- stop looking.
+            // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 13 % under the slowest pair seen has
+            // both launches in their fast modes -- stop looking.  (11.5 % until the end of round 4: it also let pairs at 2.43-2.47 ms through, whose WTA
+            // then ran at 1.23-1.25 instead of 1.17-1.19 ms; with the 64-try budget of bench.py the stricter rule costs 0-4 s: profiles/r04_placement_tries.txt.)
             // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 0.25 s per allowed try + 1 s per 20 GB of workspace in all
             // (the caller buys search time with max_tries: 3.3 s at ten tries and 15 GB).
-            if (kept < 0.885f * worst) break;
+            if (kept < 0.870f * worst) break;
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 0.25 * max_tries + (double)sp.slots * (double)sp.slot_bytes / 20e9) break;
             while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
                 (void)hipFree(held.front().p);
