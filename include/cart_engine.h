@@ -120,7 +120,7 @@ int cart_engine_device_status(cart_engine *engine, unsigned *status);
  * of at most 8 GiB - 64 MiB).
  * The call works per UNIT = the slot groups behind slots [k n, (k+1) n) of an `n_frames` call (n = min(n_frames, frames per launch)),
  * for the first (at most four) such ranges: it times the aggregation + WTA launches of n frames on the unit's current allocations, then on
- * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others; it stops early once the kept set is 11.5 % faster
+ * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others; it stops early once the kept set is 13 % faster
  * than the slowest one seen (i.e. is a fast one) or after 0.25 s per allowed try + 1 s per 20 GB of workspace.
  * TRANSIENT FOOTPRINT: candidates that lost stay allocated while the search goes on (freed at once, the allocator would hand the same
  * pages back); at no time does the call hold more than `max_extra_bytes` beyond the engine's own workspace -- 0 selects two units' worth
