@@ -32,9 +32,19 @@ class LaunchPlan(C.Structure):
     _fields_ = [("frames_per_launch", C.c_int), ("plan", C.c_int), ("slabs_written", C.c_int)]
 
 
-PLAN_AUTO, PLAN_SLABS, PLAN_FUSED_UP, PLAN_PAIRS = -1, 0, 1, 2      # CART_PLAN_*
+PLAN_AUTO, PLAN_SLABS, PLAN_FUSED_UP = -1, 0, 1      # CART_PLAN_*
 OPT_PLAN, OPT_PLAN_MIN_FRAMES, OPT_CHUNK_FRAMES = 0, 1, 2           # CART_OPT_*
 OPT_SPEC_S8_ZERO_INVALID, OPT_SPEC_S7_REPLICATE_BORDER, OPT_SPEC_S5_TOP2 = 3, 4, 5   # CART_OPT_SPEC_*: upstream variants of oracle S8 / S7 / S5
+
+
+class PlacementReport(C.Structure):
+    # mirrors cart_placement_report (include/cart_engine.h)
+    _fields_ = [("ms_first", C.c_float), ("ms_kept", C.c_float), ("ms_fastest_seen", C.c_float), ("ms_slowest_seen", C.c_float),
+                ("seconds", C.c_float), ("units", C.c_int), ("candidates", C.c_int), ("mode", C.c_int), ("stop_reason", C.c_int)]
+
+
+PLACE_MODES = {0: "unknown", 1: "fast", 2: "slow", 3: "box-slow"}                                       # CART_PLACE_MODE_*
+PLACE_STOPS = {0: "nothing to do", 1: "fast set found", 2: "box-slow", 3: "tries", 4: "time", 5: "memory"}   # CART_PLACE_STOP_*
 
 
 class SuperpixelParams(C.Structure):
@@ -54,8 +64,7 @@ PROTOTYPES = {
     "cart_engine_set_option": (_i, [_vp, _i, _i]),
     "cart_engine_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "cart_engine_describe_plan": (_i, [_vp, _i, C.POINTER(LaunchPlan)]),
-    "cart_engine_device_status": (_i, [_vp, C.POINTER(C.c_uint)]),
-    "cart_engine_tune_placement": (_i, [_vp, _i, _i, _sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "cart_engine_tune_placement": (_i, [_vp, _i, _i, _sz, C.POINTER(PlacementReport)]),
     "cart_compute_disparity": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),
     "cart_compute_disparity_batch": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp, _sz, _sz, _vp]),
     "cart_compute_disparity_multi": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _i, _vp, _sz, _vp]),

@@ -79,8 +79,8 @@ class Engine:
 
     # ---- launch plan (every plan gives the same bits; include/cart_engine.h CART_PLAN_*) ----
     def set_plan(self, plan, min_frames=1):
-        """plan: "auto" | "slabs" | "fused_up" | "pairs"; a forced plan applies to launches of >= min_frames frames."""
-        code = {"auto": _lib.PLAN_AUTO, "slabs": _lib.PLAN_SLABS, "fused_up": _lib.PLAN_FUSED_UP, "pairs": _lib.PLAN_PAIRS}[plan]
+        """plan: "auto" | "slabs" | "fused_up"; a forced plan applies to launches of >= min_frames frames."""
+        code = {"auto": _lib.PLAN_AUTO, "slabs": _lib.PLAN_SLABS, "fused_up": _lib.PLAN_FUSED_UP}[plan]
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN, code), "cart_engine_set_option")
         self._check(self._lib.cart_engine_set_option(self._h, _lib.OPT_PLAN_MIN_FRAMES, int(min_frames)), "cart_engine_set_option")
 
@@ -97,7 +97,7 @@ class Engine:
         """-> dict(frames_per_launch, plan, slabs_written) of a batched call of n_frames."""
         lp = _lib.LaunchPlan()
         self._check(self._lib.cart_engine_describe_plan(self._h, int(n_frames), C.byref(lp)), "cart_engine_describe_plan")
-        return {"frames_per_launch": lp.frames_per_launch, "plan": {0: "slabs", 1: "fused_up", 2: "pairs"}[lp.plan],
+        return {"frames_per_launch": lp.frames_per_launch, "plan": {0: "slabs", 1: "fused_up"}[lp.plan],
                 "slabs_written": lp.slabs_written}
 
     def copy_narrow(self, dst, src, workgroups=0):
@@ -112,22 +112,20 @@ class Engine:
                                                _stream_ptr()), "cart_copy_narrow")
         return dst
 
-    def tune_placement(self, n_frames, max_tries=10, max_extra_bytes=0):
+    def tune_placement(self, n_frames, max_tries=8, max_extra_bytes=0, report=False):
         """cart_engine_tune_placement (opt-in set-up step): time the slab-bound launches of an n_frames call on up to max_tries physical
         placements of the slot groups behind it and keep the fastest.  max_extra_bytes bounds what the call may hold beyond the
-        workspace while it searches (0: two units' worth; None: no cap but 4 GiB left free).  -> (ms before, ms after).  The engine
-        must be idle."""
-        a, b = C.c_float(0), C.c_float(0)
+        workspace while it searches (0: two units' worth; None: no cap but 4 GiB left free).  -> (ms before, ms after), or with
+        report=True the whole cart_placement_report as a dict (mode: fast / slow / box-slow / unknown, candidates timed, why the search
+        stopped).  The engine must be idle."""
+        r = _lib.PlacementReport()
         cap = C.c_size_t(-1).value if max_extra_bytes is None else int(max_extra_bytes)
-        self._check(self._lib.cart_engine_tune_placement(self._h, int(n_frames), int(max_tries), cap, C.byref(a), C.byref(b)), "cart_engine_tune_placement")
-        return a.value, b.value
-
-    def device_status(self):
-        """Synchronises, reads and clears the status word; 0 = healthy (bit 0: a pair sweep of plan "pairs" timed out
-        waiting for its neighbour block since the last query -- ask after synchronising when that plan is forced)."""
-        st = C.c_uint(0)
-        self._check(self._lib.cart_engine_device_status(self._h, C.byref(st)), "cart_engine_device_status")
-        return st.value
+        self._check(self._lib.cart_engine_tune_placement(self._h, int(n_frames), int(max_tries), cap, C.byref(r)), "cart_engine_tune_placement")
+        if not report:
+            return r.ms_first, r.ms_kept
+        return {"ms_first": r.ms_first, "ms_kept": r.ms_kept, "ms_fastest_seen": r.ms_fastest_seen, "ms_slowest_seen": r.ms_slowest_seen,
+                "seconds": r.seconds, "units": r.units, "candidates": r.candidates, "mode": _lib.PLACE_MODES.get(r.mode, str(r.mode)),
+                "stopped_on": _lib.PLACE_STOPS.get(r.stop_reason, str(r.stop_reason))}
 
     # ---- disparity module (reference src/modules/disparity/disparity.cu:49-80) ----
     def compute_disparity(self, left, right, out=None):

@@ -90,11 +90,6 @@ struct cart_engine {
     AggArgs agg;
     AggArgs agg_fused;              // the same launch without the "up" direction (computed inside wta_fused_kernel)
     SlabPool slab_pool;             // the cost slabs of every slot (slab_pool_alloc / slab_pool_free / cart_engine_tune_placement)
-    AggArgs agg_pairs;              // plan PAIRS: right, left, down-left, up-left (the other four ride on the two pair sweeps)
-    unsigned long long *pair_xch = nullptr;  // [max_inflight][pair_xch_elems]: block-to-block hand-over of the pair sweeps; first PAIRS call allocates
-    uint32_t *pair_ticket = nullptr;         // [max_inflight] block tickets (a lease uses the counter of its first slot)
-    uint32_t *dev_status = nullptr;          // device status word (cart_engine_device_status)
-    uint32_t pair_epoch = 0;                 // guarded by mu; tags the hand-over words of one sweep launch
     int auto_fused_min_frames = 1 << 30; // CART_OPT_PLAN = auto: launches of at least this many frames take the fused WTA
     int opt_plan = CART_PLAN_AUTO;       // cart_engine_set_option
     int opt_plan_min_frames = 1;         // with a forced plan: launches of fewer frames still take CART_PLAN_SLABS
@@ -228,9 +223,6 @@ int plan_for(const cart_engine *e, const Options &o, int n) {
     if (o.spec & 4) return CART_PLAN_SLABS;   // the S5 variant exists in the two-kernel WTA only
     if (o.plan == CART_PLAN_AUTO) return n >= e->auto_fused_min_frames ? CART_PLAN_FUSED_UP : CART_PLAN_SLABS;
     if (n < o.plan_min_frames) return CART_PLAN_SLABS;
-    // PAIRS stores the sum of two penalty parts in a byte and needs the diagonals: other engines take FUSED_UP.  So do
-    // images whose sink offset does not fit the sweep's 32-bit lane offsets (pairs_offsets_fit).
-    if (o.plan == CART_PLAN_PAIRS && !(e->g.P == 8 && 2 * e->g.p2 <= 255 && pairs_offsets_fit(e->g))) return CART_PLAN_FUSED_UP;
     return o.plan;
 }
 
@@ -265,6 +257,10 @@ int dev_alloc(T **p, size_t count) {
 // the range inaccessible; a range re-reserved while other ranges are live did the same) and is gone: nothing in the engine calls
 // hipMemAddressReserve / hipMemMap any more.
 constexpr size_t kSlabChunkBytes = ((size_t)8 << 30) - ((size_t)64 << 20);
+// cart_engine_tune_placement: a kept placement this far under the slowest one seen is a fast one; after kBoxSlowAfter timed placements that
+// are all within (1 - kBoxSlowRatio) of each other the box has no fast placement to offer
+constexpr float kPlaceFastRatio = 0.870f, kBoxSlowRatio = 0.950f;
+constexpr int kBoxSlowAfter = 6;
 
 void slab_pool_free(SlabPool &sp) {
     for (uint8_t *b : sp.base)
@@ -295,9 +291,12 @@ int slab_pool_alloc(SlabPool &sp, size_t slot_bytes, int slots) {
 }
 
 // slab pointers of the n frames of one launch at slots [s0, s0 + n); `subst` (may be null) replaces the base of some groups (placement probes)
+// A range that does not lie inside the pool (a caller passing a wrong s0 / n) yields an EMPTY table (frame[0] == nullptr) and the callers fail
+// on the host: a launch must never see a pointer computed from a slot the pool does not hold (profiles/r04_vmm_faults.txt, fault 3).
 SlabTable slab_table(const SlabPool &sp, int s0, int n, const std::vector<uint8_t *> *subst = nullptr) {
     SlabTable t{};
-    for (int f = 0; f < n && f < kMaxLaunchFrames; ++f) {
+    if (s0 < 0 || n < 1 || n > kMaxLaunchFrames || s0 + n > sp.slots || sp.group_slots < 1) return t;
+    for (int f = 0; f < n; ++f) {
         const int s = s0 + f, gi = s / sp.group_slots;
         uint8_t *b = subst && (*subst)[gi] ? (*subst)[gi] : sp.base[gi];
         t.frame[f] = b + (size_t)(s % sp.group_slots) * sp.slot_bytes;
@@ -392,7 +391,6 @@ int cart_engine_create(const cart_engine_params *params, cart_engine **out) {
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { cart_engine_destroy(e); return fail("building the uniqueness table failed"); }
     build_agg_args(e, e->agg, 0xffu);
     build_agg_args(e, e->agg_fused, 0xffu & ~(1u << 3));  // launch-order slot 3 = {0,-1} = "up" (slab kFusedUpPath)
-    build_agg_args(e, e->agg_pairs, 0x63u);               // launch-order slots 0, 1 (right, left), 5 (down-left), 6 (up-left)
     // Fused WTA (the "up" direction computed inside the WTA sweep, 1/P less slab traffic): measured on MI355X at
     // 1242x375, batch 16 (profiles/tools/disparity_only.py): D=256 -9 % (4 paths) / -15 % (8 paths) per batch, D=128
     // even, D=64 +4..6 %; D=256 batches of 4 frames: +5 % at 1242x375, -11 % at 1920x1080 -- so it is the default for
@@ -411,8 +409,7 @@ void cart_engine_destroy(cart_engine *e) {
     (void)hipSetDevice(e->params.device_id);   // the caller's current device may be another one
     (void)hipDeviceSynchronize();
     slab_pool_free(e->slab_pool);
-    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws,
-                    e->pair_xch, e->pair_ticket, e->dev_status, e->uniq_thr};
+    void *bufs[] = {e->gray_l, e->gray_r, e->cen_l_alloc, e->cen_r_alloc, e->wta_l, e->right_pk, e->tmp_a, e->tmp_b, e->ccl_work, e->sp_votes, e->rv_partial, e->flow_ws, e->ccl_stats_ws, e->uniq_thr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &s : e->slots) {
@@ -437,7 +434,7 @@ int cart_engine_set_option(cart_engine *e, int option, int value) {
     std::lock_guard<std::mutex> lk(e->mu);
     switch (option) {
         case CART_OPT_PLAN:
-            if (value < CART_PLAN_AUTO || value > CART_PLAN_PAIRS) return fail("unknown plan");
+            if (value < CART_PLAN_AUTO || value > CART_PLAN_FUSED_UP) return fail("unknown plan");
             e->opt_plan = value;
             return 0;
         case CART_OPT_PLAN_MIN_FRAMES:
@@ -482,7 +479,7 @@ int cart_engine_describe_plan(cart_engine *e, int n_frames, cart_launch_plan *ou
     const Options o = snapshot_options(e);
     out->frames_per_launch = std::min(n_frames, o.chunk_frames);
     out->plan = plan_for(e, o, out->frames_per_launch);
-    out->slabs_written = out->plan == CART_PLAN_PAIRS ? 6 : out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
+    out->slabs_written = out->plan == CART_PLAN_FUSED_UP ? e->g.P - 1 : e->g.P;
     return 0;
 }
 
@@ -491,6 +488,7 @@ namespace {
 // warm-up; the census planes hold whatever they hold: the cost of these launches does not depend on the data).  < 0 on error.
 float probe_placement(cart_engine *e, const Options &opt, const SlabTable &slabs, size_t s0, int n, hipEvent_t ev0, hipEvent_t ev1) {
     const Geometry &g = e->g;
+    if (!slabs.frame[0]) return -1.f;   // slot range outside the pool (slab_table)
     uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
     uint16_t *wl = e->wta_l + s0 * g.npx;
     uint32_t *rpk = e->right_pk + s0 * g.npx;
@@ -513,12 +511,11 @@ float probe_placement(cart_engine *e, const Options &opt, const SlabTable &slabs
 }
 }  // namespace
 
-int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size_t max_extra_bytes, float *ms_first, float *ms_kept) {
+int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size_t max_extra_bytes, cart_placement_report *report) {
+    if (report) std::memset(report, 0, sizeof(*report));
     if (!e) return fail("engine is NULL");
     if (e->post_only) return fail("this engine was created without SGM workspaces (num_disparities = 0)");
     if (n_frames < 1 || n_frames > (int)e->slots.size()) return fail("n_frames must be in [1, max_inflight]");
-    if (ms_first) *ms_first = 0.f;
-    if (ms_kept) *ms_kept = 0.f;
     HIP_TRY(hipSetDevice(e->params.device_id));
     std::unique_lock<std::mutex> lk(e->mu);
     for (const auto &sl : e->slots)
@@ -534,7 +531,8 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
     SlabPool &sp = e->slab_pool;
     // The search runs per UNIT = the groups behind the slots [k n, (k + 1) n) of one n-frame call, for the first (at most four) such
     // ranges: a lease takes the lowest free range its stream used last (acquire), so a caller with one call in flight lives in unit 0
-    // and one with several walks up the units.  A group already settled by an earlier unit is not touched again.
+    // and one with several walks up the units.  A group already settled by an earlier unit is not touched again.  A group that holds
+    // more slots than the launch has frames (32-slot groups, 16-frame launches) is scored on the slots of its first launch only.
     const int units = std::max(1, std::min(4, (int)e->slots.size() / n));
     std::vector<char> settled((size_t)sp.groups(), 0);
     // Candidates that lost stay allocated while the search goes on (freed at once, their pages would come straight back from the
@@ -543,9 +541,14 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
     std::vector<Held> held;
     size_t extra = 0;
     const auto t_begin = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 0.25 s per allowed try + 1 s per 20 GB of workspace in all (the caller
+    // buys search time with max_tries), and every unit gets its own share of that, so that unit 0 cannot spend what units 1-3 were promised.
+    const double unit_budget = (0.25 * max_tries + (double)sp.slots * (double)sp.slot_bytes / 20e9) / units;
     double sum_first = 0.0, sum_kept = 0.0;
-    int rc = 0, probed = 0;
+    int rc = 0, probed = 0, total_candidates = 0;
     for (int u = 0; u < units && rc == 0; ++u) {
+        const auto t_unit = std::chrono::steady_clock::now();
         const int s0 = u * n, g0 = s0 / sp.group_slots, g1 = (s0 + n - 1) / sp.group_slots;
         std::vector<int> mine;
         size_t unit_bytes = 0;
@@ -556,24 +559,26 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
         sum_first += kept;
         ++probed;
         float worst = kept;
+        int seen = 1, stop = mine.empty() ? CART_PLACE_STOP_NOTHING_TO_DO : CART_PLACE_STOP_TRIES;
         // at most this many bytes beyond the workspace at any time (0 = two units' worth); SIZE_MAX = whatever leaves 4 GiB free
         const size_t cap = max_extra_bytes ? max_extra_bytes : 2 * unit_bytes;
         for (int t = 1; t < max_tries && !mine.empty(); ++t) {
             // Each launch has a fast and a slow mode 8-10 % apart (and levels in between): a placement 13 % under the slowest pair seen has
-            // both launches in their fast modes -- stop looking.  (11.5 % until the end of round 4: it also let pairs at 2.43-2.47 ms through, whose WTA
-            // then ran at 1.23-1.25 instead of 1.17-1.19 ms; with the 64-try budget of bench.py the stricter rule costs 0-4 s: profiles/r04_placement_tries.txt.)
-            // Allocating tens of GB takes 0.1-0.6 s per candidate: no more than 0.25 s per allowed try + 1 s per 20 GB of workspace in all
-            // (the caller buys search time with max_tries: 3.3 s at ten tries and 15 GB).
-            if (kept < 0.870f * worst) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 0.25 * max_tries + (double)sp.slots * (double)sp.slot_bytes / 20e9) break;
+            // both launches in their fast modes -- stop looking (profiles/r04_placement_tries.txt).
+            if (kept < kPlaceFastRatio * worst) { stop = CART_PLACE_STOP_FAST_FOUND; break; }
+            // A box on which no placement is fast (round 4's driver box: 64 candidates between 2.57 and 2.60 ms, 7.7 s of search for 1.4 %; one
+            // builder box in ~20: every candidate >= 2.71 ms): once kBoxSlowAfter placements have been timed and the fastest is within 5 % of the
+            // slowest, there is nothing to find here -- keep the best seen and stop.
+            if (seen >= kBoxSlowAfter && kept > kBoxSlowRatio * worst) { stop = CART_PLACE_STOP_BOX_SLOW; break; }
+            if (seconds_since(t_unit) > unit_budget) { stop = CART_PLACE_STOP_TIME; break; }
             while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
                 (void)hipFree(held.front().p);
                 extra -= held.front().bytes;
                 held.erase(held.begin());
             }
-            if (extra + unit_bytes > cap) break;
+            if (extra + unit_bytes > cap) { stop = CART_PLACE_STOP_MEMORY; break; }
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < unit_bytes + ((size_t)4 << 30)) break;   // no room for another candidate
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < unit_bytes + ((size_t)4 << 30)) { stop = CART_PLACE_STOP_MEMORY; break; }   // no room for another candidate
             std::vector<uint8_t *> cand((size_t)sp.groups(), nullptr);
             bool ok = true;
             for (int gi : mine)
@@ -581,6 +586,7 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
             if (!ok) {
                 (void)hipGetLastError();
                 for (int gi : mine) if (cand[(size_t)gi]) (void)hipFree(cand[(size_t)gi]);
+                stop = CART_PLACE_STOP_MEMORY;
                 break;
             }
             extra += unit_bytes;
@@ -591,6 +597,7 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
                 rc = fail("placement probe failed");
                 break;
             }
+            ++seen;
             worst = std::max(worst, sc);
             const bool better = sc < kept;
             for (int gi : mine) {   // the loser of every group joins the held list
@@ -600,27 +607,29 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
             }
             if (better) kept = sc;
         }
+        if (stop == CART_PLACE_STOP_TRIES && kept < kPlaceFastRatio * worst) stop = CART_PLACE_STOP_FAST_FOUND;   // the last allowed try was the fast one
         sum_kept += kept;
+        total_candidates += seen;
+        if (u == 0 && report && rc == 0) {   // the unit a caller with one call in flight lives in
+            report->stop_reason = stop;
+            report->mode = kept < kPlaceFastRatio * worst ? CART_PLACE_MODE_FAST
+                         : (seen >= kBoxSlowAfter && kept > kBoxSlowRatio * worst) ? CART_PLACE_MODE_BOX_SLOW
+                         : seen == 1 ? CART_PLACE_MODE_UNKNOWN : CART_PLACE_MODE_SLOW;
+            report->ms_fastest_seen = kept;
+            report->ms_slowest_seen = worst;
+        }
     }
     (void)hipDeviceSynchronize();
     for (auto &h : held) (void)hipFree(h.p);
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    if (probed && rc == 0) {   // mean over the probed units, before and after
-        if (ms_first) *ms_first = (float)(sum_first / probed);
-        if (ms_kept) *ms_kept = (float)(sum_kept / probed);
+    if (probed && rc == 0 && report) {   // mean over the probed units, before and after
+        report->ms_first = (float)(sum_first / probed);
+        report->ms_kept = (float)(sum_kept / probed);
+        report->units = probed;
+        report->candidates = total_candidates;
+        report->seconds = (float)seconds_since(t_begin);
     }
     return rc;
-}
-
-int cart_engine_device_status(cart_engine *e, unsigned *status) {
-    if (!e || !status) return fail("bad arguments");
-    *status = 0;
-    if (!e->dev_status) return 0;   // no kernel that can raise it has run
-    HIP_TRY(hipSetDevice(e->params.device_id));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(status, e->dev_status, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (*status) HIP_TRY(hipMemset(e->dev_status, 0, sizeof(unsigned)));   // read-and-clear: a report covers the calls since the last query
-    return 0;
 }
 
 int cart_engine_set_timing(cart_engine *e, int enabled) {
@@ -709,18 +718,6 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         const int launch_plan = plan_for(e, opt, std::min(n_frames, opt.chunk_frames));   // later (shorter) launches of the call never need more
         if (launch_plan == CART_PLAN_FUSED_UP && !e->rv_partial)
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->rv_partial), e->slots.size() * wta_fused_partial_elems(g) * sizeof(uint32_t)));
-        if (launch_plan == CART_PLAN_PAIRS && !e->pair_xch) {
-            // zeroed once: epoch 0 never tags a launch, so a word that was never written cannot pass for a hand-over
-            const size_t words = 2 * e->slots.size() * pair_xch_elems(g);   // one area per sweep direction: they run concurrently
-            if (!e->pair_ticket) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->pair_ticket), 2 * e->slots.size() * sizeof(uint32_t)));
-            HIP_TRY(hipMemset(e->pair_ticket, 0, 2 * e->slots.size() * sizeof(uint32_t)));
-            if (!e->dev_status) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->dev_status), sizeof(uint32_t)));
-            HIP_TRY(hipMemset(e->dev_status, 0, sizeof(uint32_t)));
-            unsigned long long *xch = nullptr;   // published last: the launches below take e->pair_xch as "everything is there"
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&xch), words * sizeof(unsigned long long)));
-            if (hipMemset(xch, 0, words * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(xch); return fail("hipMemset of the hand-over area failed"); }
-            e->pair_xch = xch;
-        }
     }
     Lease l;
     if (acquire(e, n_frames, stream, &l)) return -1;
@@ -735,8 +732,10 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     const bool smooth = radius > 0 && iters > 0;  // disparity.cu:73
     const size_t tight_step = (size_t)g.w * 2, tight_fs = g.npx * 2;
     // Enqueues every stage for frames [f0, f0+n) of this call on stream `st`.
+    bool bad_slots = false;
     auto enqueue = [&](int f0, int n, hipStream_t st, bool timed) {
         const size_t s0 = (size_t)l.s0 + f0;
+        if (!slab_table(e->slab_pool, (int)s0, n).frame[0]) { bad_slots = true; return; }   // nothing is launched on a slot range the pool does not hold
         uint8_t *gl = e->gray_l + s0 * g.npx, *gr = e->gray_r + s0 * g.npx;
         uint32_t *cl = e->cen_l + s0 * g.census_elems, *cr = e->cen_r + s0 * g.census_elems;
         const SlabTable slabs = slab_table(e->slab_pool, (int)s0, n);
@@ -750,33 +749,13 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
         STAGE("census");
         launch_census(fr.images(false, f0, n), fr.images(true, f0, n), channels, n, gl, gr, cl, cr, rpk, g, st);
         const int launch_plan = plan_for(e, opt, n);
-        const bool pairs = launch_plan == CART_PLAN_PAIRS && e->pair_xch;
         const bool fused = launch_plan == CART_PLAN_FUSED_UP && e->rv_partial;
-        STAGE(pairs ? "pair_down" : "aggregate");
-        if (pairs) {
-            // {down, down-right} -> slab 0, {up, up-right} -> slab 1 (penalty sums); slab 4 takes the stores of columns >= w
-            uint32_t epoch;
-            {
-                std::lock_guard<std::mutex> lk(e->mu);
-                e->pair_epoch += 2;
-                if (e->pair_epoch == 0) e->pair_epoch = 2;   // epoch 0 is the never-written state
-                epoch = e->pair_epoch;
-            }
-            // Both sweeps on the caller's stream, one after the other.  Running them on side streams beside the 4-direction
-            // launch was measured (profiles/README.md, round 2): 3.8 instead of 3.6 ms per 16 pairs -- resident blocks that wait
-            // for their neighbour hold their wave slots, so the other kernels do not get the idle issue slots.
-            for (int k = 0; k < 2; ++k) {
-                unsigned long long *xch = e->pair_xch + (2 * s0 + k * (size_t)n) * pair_xch_elems(g);
-                launch_pair_sweep(cl, cr, slabs, xch, e->pair_ticket + 2 * s0 + k, e->dev_status, g, epoch + k, k == 0 ? +1 : -1, k, 4, n, st);
-                STAGE(k == 0 ? "pair_up" : "aggregate");
-            }
-        }
-        AggArgs a = pairs ? e->agg_pairs : fused ? e->agg_fused : e->agg;
+        STAGE("aggregate");
+        AggArgs a = fused ? e->agg_fused : e->agg;
         a.cen_l = cl; a.cen_r = cr; a.slabs = slabs;
         launch_aggregate(a, n, st);
         STAGE("wta");
-        if (pairs) launch_wta_pairs(slabs, cl, cr, wl, rpk, g, e->uniq_thr, n, st);
-        else if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, st);
+        if (fused) launch_wta_fused(cl, cr, slabs, wl, rpk, e->rv_partial + s0 * wta_fused_partial_elems(g), g, e->uniq_thr, n, st);
         else launch_wta(slabs, wl, rpk, g, e->uniq_thr, n, st, (opt.spec & 4) != 0);
         STAGE("post");
         if (!smooth) {
@@ -807,6 +786,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     for (int f0 = 0; f0 < n_frames; f0 += chunk) enqueue(f0, std::min(chunk, n_frames - f0), stream, f0 == 0);
     hipError_t err = hipGetLastError();
     release(l);
+    if (bad_slots) return fail("internal error: a launch's slot range lies outside the slab pool");
     if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
     return 0;
 }

@@ -90,16 +90,6 @@ void launch_aggregate(const AggArgs &a, int n_frames, hipStream_t s);
 // thr = device table of the integer uniqueness threshold for every best cost 0..2047 (launch_uniq_table, built once per engine)
 void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, const Geometry &g, const uint16_t *thr,
                 int n_frames, hipStream_t s, bool top2 = false);   // top2: the S5 variant (second-best only), two-kernel WTA only
-// plan PAIRS (sgm_kernels.hip): one sweep per vertical direction carries that direction and the diagonal leaning the same way
-size_t pair_xch_elems(const Geometry &g);   // 8-byte words of the per-frame hand-over buffer
-void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
-                       const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s);
-void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
-                      const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s);
-// The sweep addresses its slab stores as "wave-uniform base + 32-bit lane offset"; lanes of columns >= w are sent to the
-// same cell of the sink slab, (sink - out) <= 4 slabs further on.  That offset plus one image row of columns has to fit 32
-// bits (w*h*D < ~2^30: e.g. 2048x2048 at D=256 and 4096x2160 at D=128 do not); plan_for() gives such engines FUSED_UP.
-inline bool pairs_offsets_fit(const Geometry &g) { return 4 * (unsigned long long)g.slab_bytes + (unsigned long long)g.w * g.D < (1ull << 32); }
 // WTA fused with the "up" direction (slab kFusedUpPath is never read: the aggregate launch may skip that direction)
 constexpr int kFusedUpPath = 1;
 size_t wta_fused_partial_elems(const Geometry &g);  // u32 elements of the per-frame right-view partial buffer

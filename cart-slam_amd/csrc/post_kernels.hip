@@ -812,6 +812,6 @@ void launch_narrow_copy(const void *src, void *dst, size_t bytes, int blocks, hi
     hipLaunchKernelGGL(narrow_copy_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), bytes);
 }
 
-int kernel_count() { return 67; }  // device kernels in the library (counted from the generated ISA): sgm_kernels 38 (census, aggregate x6, pair_sweep x6, wta x9, wta_fused x8, rv_merge x6, post, uniq_table) + post_kernels 18 + superpixel_kernels 8 + flow 3
+int kernel_count() { return 58; }  // device kernels in the library (counted from the generated ISA): sgm_kernels 29 (census, aggregate x6, wta x6, wta_fused x8, rv_merge x6, post, uniq_table) + post_kernels 18 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

@@ -558,7 +558,14 @@ __device__ __forceinline__ void hsplit_producer(const uint32_t *pl, unsigned lo_
 }
 
 // lanes 32..63 of `a` <-> lanes 0..31 of `b` (gfx950's v_permlane32_swap): a = {a.lo, b.lo}, b = {a.hi, b.hi}
-__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// (gfx950 only, like pk_min3: any other --offload-arch stops here instead of failing in the assembler)
+__device__ __forceinline__ void swap_halves(uint32_t &a, uint32_t &b) {
+#if defined(__gfx950__)
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+#elif defined(__HIP_DEVICE_COMPILE__)
+#error "sgm_kernels.hip is written for gfx950 (v_permlane32_swap_b32)"
+#endif
+}
 
 // consumer of a pair.  D = 64 (LPP = 4): a pixel is 64 bytes, half a 128-byte line, and a step's store would write 16 rows x 64 B; the stores of TWO
 // steps are regrouped instead (four lane-half swaps) so that each instruction writes whole lines: rows 0-7 of both steps, then rows 8-15 (lo_a / lo_b:
@@ -665,7 +672,9 @@ __global__ __launch_bounds__(64 * kAggWaves, (LPP >= 8 && !HS) ? 6 : 4) void agg
         __builtin_amdgcn_s_setprio(3);
         if constexpr (HS) {
             // rows past the image (the last wave pair of a direction) clone the pair's last valid row: same reads, same bytes to the same cells,
-            // and every wave that entered reaches every barrier
+            // and every wave that entered reaches every barrier.  Two waves then store to the same slab cells without ordering: benign only because
+            // both compute the same state from the same census rows -- held by tests/test_gpu_parity.py::test_split_horizontal_scans_equal_plain_ones,
+            // whose heights leave the last workgroup a partial pair and an idle pair (every slab row, the cloned ones included, against the oracle)
             const int l0 = min(line0, nlines - 1), pgv = min(pg, nlines - l0 - 1);   // (a pair wholly past the image clones the last row)
             const int y0s = a.dirs[di].jmin + l0, xs = dx > 0 ? 0 : g.w - 1;
             const uint32_t *pls = a.cen_l + uniform((ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)y0s * g.cpitch + g.cpadl + xs);
@@ -945,254 +954,6 @@ void launch_aggregate(const AggArgs &a_in, int n_frames, hipStream_t s) {
 }
 
 
-// ------------------------------------------------------------------ pair sweeps (launch plan PAIRS)
-// A vertical direction and the diagonal that leans the same way ({down, down-right} or {up, up-right}) are carried by ONE
-// sweep over the image rows: both need the matching cost of the same pixel (computed once) and their penalty parts
-//   s_r(p,d) = L_r(p,d) - C(p,d) = min(L_r(p-r,d), L_r(p-r,d+-1)+P1, min_k L_r(p-r,k)+P2) - min_k L_r(p-r,k)  in [0, P2]
-// are added and stored as ONE u8 slab (2*P2 <= 255): D bytes per pixel instead of 2*D written and 2*D read.  The WTA adds the
-// 2*C the two paths share back from the census planes (wta_kernel<LPP, true>).
-//
-// Column ownership: a wave owns P = 64/LPP adjacent columns for the whole sweep, lane group g = column x0 + wave*P + g.
-// The vertical path's state stays in the lanes.  The diagonal path of column x continues from column x-1 of the previous
-// row, so its state moves ONE LANE GROUP to the right per row: every lane writes its 8 packed state registers + min to an
-// LDS array indexed by block lane and reads them back LPP lanes lower (one s_barrier per row, double buffered).  The
-// entries below lane 0 are the block's inbox: the state of the last column of the block to the left.
-//
-// Across blocks the dependency only runs left -> right ((b, row) needs (b-1, row-1)), so the blocks of a frame form a
-// pipeline, not a lock-step: block b-1 runs ahead and b never waits once it lags by a row plus the hand-over latency.  The
-// hand-over goes through global memory, done by a HELPER wave per block (no slab stores in its VMEM queue, so its waits are
-// short and the compute waves keep their counted prefetch pipeline): after row t it reads the block's last column from LDS
-// and publishes it as 5 x 8-byte words {payload, epoch} (relaxed agent-scope atomics: an 8-byte store is single-copy
-// atomic, so a word that carries this launch's epoch carries this launch's payload -- no fence, no flag); before row t+1 it
-// polls the left neighbour's words of row t and puts them into the inbox.  Blocks take their position from a ticket
-// (atomic counter), so a block's left neighbour has always started before it: the pipeline cannot deadlock however many
-// blocks are resident.  Polls are bounded: on a timeout the block raises the status word, stops polling and drains.
-constexpr int kPairWaves = 4;   // compute waves per block (+ 1 helper)
-constexpr uint32_t kPairSpinMax = 1u << 20;
-template <int LPP> constexpr int pair_cols() { return kPairWaves * (64 / LPP); }
-
-struct PairArgs {
-    const uint32_t *cen_l, *cen_r;
-    SlabTable slabs;               // per frame: [path][h][w][D]
-    unsigned long long *xch;       // [frame][blk][row][LPP][5] {payload, epoch}
-    uint32_t *ticket;              // one counter per launch (reset by the block that draws the last ticket)
-    uint32_t *status;              // device status word: non-zero after a hand-over timeout
-    Geometry g;
-    uint32_t epoch;
-    int out_path, sink_path;       // slab that receives the pair sum; slab no plan-PAIRS kernel uses (stores of columns >= w)
-    int nblk;
-};
-
-// one path step on precomputed cost pairs c[i] = (C[d0+8+i] << 16 | C[d0+i]); uo receives the penalty parts (L - C)
-template <int LPP>
-__device__ __forceinline__ void pair_step(uint32_t (&a)[8], uint32_t &mm, const uint32_t (&c)[8], uint32_t sel_lo, uint32_t sel_hi,
-                                          uint32_t p1p1, uint32_t p2p2, uint32_t (&uo)[8]) {
-    const uint32_t mp2 = mm + p2p2;
-    const uint32_t lo0 = perm(a[7], dpp_mov<DPP_ROW_SHR1>(a[7]), sel_lo);
-    const uint32_t hi7 = perm(dpp_mov<DPP_ROW_SHL1>(a[0]), a[0], sel_hi);
-    uint32_t n[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t lo = i == 0 ? lo0 : a[i - 1];
-        const uint32_t hi = i == 7 ? hi7 : a[i + 1];
-        uint32_t t = pk_min(lo, hi) + p1p1;
-        t = pk_min3(t, a[i], mp2);
-        uo[i] = t - mm;            // both halves >= m: plain subtract (see agg_step)
-        n[i] = uo[i] + c[i];
-    }
-    uint32_t x = pk_min(pk_min3(n[0], n[1], n[2]), pk_min3(n[3], n[4], pk_min3(n[5], n[6], n[7])));
-    x = pk_min(x, __builtin_amdgcn_alignbit(x, x, 16));
-    mm = group_allmin<LPP>(x);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = n[i];
-}
-
-template <int LPP, int DY>
-__global__ __launch_bounds__(64 * (kPairWaves + 1)) void pair_sweep_kernel(PairArgs a) {
-    using WN = Win<LPP>;
-    constexpr int P = WN::P, D = WN::D, NT = 64 * kPairWaves, COLS = kPairWaves * P;
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t s_win[kPairWaves][2][WN::BUF];
-    __shared__ uint32_t s_shift[2][9][LPP + NT];
-    __shared__ uint32_t s_ticket;
-    const Geometry &g = a.g;
-    keep_f16_denormals();
-    const int tid = threadIdx.x, lane = tid & 63, wid = uniform((int)(threadIdx.x >> 6));
-    if (tid == 0) {
-        const uint32_t t = atomicAdd(a.ticket, 1u);
-        if (t == gridDim.x - 1) *a.ticket = 0u;   // every block has drawn: ready for the next launch on this lease
-        s_ticket = t;
-    }
-    for (int i = tid; i < 2 * 9 * (LPP + NT); i += 64 * (kPairWaves + 1)) (&s_shift[0][0][0])[i] = 0u;   // zero state = path start
-    __syncthreads();
-    const int lb = (int)s_ticket;
-    const int frame = lb / a.nblk, blk = lb - frame * a.nblk, x0 = blk * COLS;
-    const int ys = DY > 0 ? 0 : g.h - 1;   // row of step 0
-
-    if (wid == kPairWaves) {
-        // ---- helper wave: hand-over between blocks; lane gl < LPP handles disparity chunk gl of the edge column
-        const bool has_left = blk > 0, has_right = blk + 1 < a.nblk;
-        unsigned long long *mine = a.xch + ((size_t)frame * a.nblk + blk) * (size_t)g.h * LPP * 5;
-        const unsigned long long *left = mine - (size_t)g.h * LPP * 5;
-        bool dead = false;   // a poll timed out: stop polling, let the grid drain
-        for (int t = 0; t < g.h; ++t) {
-            if (has_left && lane < LPP) {
-                const unsigned long long *src = left + ((size_t)t * LPP + lane) * 5;
-                uint32_t pay[5] = {0, 0, 0, 0, 0};
-                if (!dead) {
-                    bool ok = false;
-                    for (uint32_t it = 0; it < kPairSpinMax && !ok; ++it) {
-                        ok = true;
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) {
-                            const unsigned long long v = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            pay[k] = (uint32_t)v;
-                            ok &= (uint32_t)(v >> 32) == a.epoch;
-                        }
-                        if (!ok) __builtin_amdgcn_s_sleep(4);
-                    }
-                    if (!ok) { dead = true; atomicOr(a.status, 1u); }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s_shift[t & 1][2 * k][lane] = perm(0u, pay[k], 0x0c010c00u);
-                    s_shift[t & 1][2 * k + 1][lane] = perm(0u, pay[k], 0x0c030c02u);
-                }
-                s_shift[t & 1][8][lane] = (pay[4] & 0xffu) * 0x10001u;
-            }
-            dead = __builtin_amdgcn_readfirstlane(__any((int)dead));   // wave-uniform
-            lds_barrier();   // barrier(t): the compute waves have written the state of row t
-            if (has_right && lane < LPP) {
-                const int src_lane = LPP + NT - LPP + lane;   // the block's last column
-                unsigned long long *dst = mine + ((size_t)t * LPP + lane) * 5;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t b = perm(s_shift[t & 1][2 * k + 1][src_lane], s_shift[t & 1][2 * k][src_lane], 0x06040200u);
-                    __hip_atomic_store(dst + k, ((unsigned long long)a.epoch << 32) | b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(dst + 4, ((unsigned long long)a.epoch << 32) | (s_shift[t & 1][8][src_lane] & 0xffu), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-
-    // ---- compute waves
-    const int gl = lane % LPP, pg = lane / LPP, d0 = gl * 16;
-    const int xw0 = x0 + wid * P, x = xw0 + pg;   // wave's first column (uniform), this lane group's column
-    const bool valid = x < g.w;
-    const uint32_t p1p1 = (uint32_t)g.p1 * 0x10001u, p2p2 = (uint32_t)g.p2 * 0x10001u;
-    const uint32_t sel_lo = gl == 0 ? 0x05040d0du : 0x05040302u;
-    const uint32_t sel_hi = gl == LPP - 1 ? 0x0d0d0302u : 0x05040302u;
-
-    WinLane<LPP> wlane;
-    wlane.init(lane);
-    unsigned (&goff)[WN::NLD] = wlane.goff;
-    const int (&lslot)[WN::NLD] = wlane.lslot;
-    const int rbase = wlane.rbase;
-    uint32_t *buf0 = &s_win[wid][0][0], *buf1 = &s_win[wid][1][0];
-
-    const ptrdiff_t cstride = (ptrdiff_t)DY * g.cpitch;
-    const ptrdiff_t ostride = (ptrdiff_t)DY * g.w * D;
-    const ptrdiff_t cen_off = (ptrdiff_t)frame * (ptrdiff_t)g.census_elems + (ptrdiff_t)ys * g.cpitch + g.cpadl + xw0;
-    const uint32_t *pw = a.cen_r + uniform(cen_off - g.min_disp - (D - 1));
-    const uint32_t *pl = a.cen_l + uniform(cen_off);
-    // slab addressing: uniform base of the wave's first column (clamped into the image) + lane offset; columns past the
-    // image store into the same cell of a slab this plan never reads.  The sink offset is a 32-bit lane offset: the
-    // engine only takes this plan when pairs_offsets_fit(g) (engine_internal.h), i.e. 4 slabs + a row stay below 2^32
-    const int xbase = min(xw0, g.w - 1), xc = min(x, g.w - 1);
-    uint8_t *po = a.slabs.frame[frame] + uniform((ptrdiff_t)a.out_path * (ptrdiff_t)g.slab_bytes + ((ptrdiff_t)ys * g.w + xbase) * D);
-    unsigned lo_l = (unsigned)pg * 4u;
-    unsigned lo_o = (unsigned)((xc - xbase) * D + d0) + (valid ? 0u : (unsigned)(a.sink_path - a.out_path) * (unsigned)g.slab_bytes);
-
-    uint32_t stV[8], stD[8], mmV = 0, mmD = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) stV[i] = stD[i] = 0;
-
-    auto step = [&](int t, const uint32_t *wbuf, uint32_t fl, CART_GLOBAL uint8_t *dst) {
-        CensusRegs c;
-        c.fl = fl;
-        win_read<LPP>(wbuf, rbase, c.r);
-        uint32_t cost[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            cost[i] = ((uint32_t)__builtin_popcount(c.fl ^ c.r[7 - i]) << 16) + (uint32_t)__builtin_popcount(c.fl ^ c.r[15 - i]);
-        uint32_t uV[8], uD[8];
-        pair_step<LPP>(stV, mmV, cost, sel_lo, sel_hi, p1p1, p2p2, uV);
-        const int pb = (t + 1) & 1, cb = t & 1;   // previous row's buffer (row -1 = the zeroed one), this row's
-#pragma unroll
-        for (int i = 0; i < 8; ++i) stD[i] = s_shift[pb][i][tid];   // = lane tid - LPP of the previous row (inbox below lane 0)
-        mmD = s_shift[pb][8][tid];
-        pair_step<LPP>(stD, mmD, cost, sel_lo, sel_hi, p1p1, p2p2, uD);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s_shift[cb][i][LPP + tid] = stD[i];
-        s_shift[cb][8][LPP + tid] = mmD;
-        uint32_t s[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s[i] = uV[i] + uD[i];   // halves <= 2*P2 <= 255
-        const v4u q = {perm(s[1], s[0], 0x06040200u), perm(s[3], s[2], 0x06040200u), perm(s[5], s[4], 0x06040200u), perm(s[7], s[6], 0x06040200u)};
-        __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)dst);
-        lds_barrier();
-    };
-
-    // software pipeline as in aggregate_kernel: the loads of step t+2 are issued before the store of step t
-    uint32_t g0[WN::NLD], g1[WN::NLD], f0, f1;
-#pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = ld_u32(pw, goff[i]);
-    f0 = ld_u32(pl, lo_l);
-#pragma unroll
-    for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + cstride, goff[i]);
-    f1 = ld_u32(pl + cstride, lo_l);
-    int t = 0;
-    for (; t + 1 < g.h; t += 2) {
-#pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) g0[i] = ld_u32(pw + 2 * cstride, goff[i]);
-        const uint32_t fa = f0;
-        f0 = ld_u32(pl + 2 * cstride, lo_l);
-        __builtin_amdgcn_sched_barrier(0);
-        step(t, buf0, fa, sgpr(po) + pin_v(lo_o));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf1[lslot[i]] = g1[i];
-#pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) g1[i] = ld_u32(pw + 3 * cstride, goff[i]);
-        const uint32_t fb = f1;
-        f1 = ld_u32(pl + 3 * cstride, lo_l);
-        __builtin_amdgcn_sched_barrier(0);
-        step(t + 1, buf1, fb, sgpr(po + ostride) + pin_v(lo_o));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < WN::NLD; ++i) buf0[lslot[i]] = g0[i];
-        pw += 2 * cstride; pl += 2 * cstride; po += 2 * ostride;
-    }
-    if (t < g.h) step(t, buf0, f0, sgpr(po) + pin_v(lo_o));
-}
-
-size_t pair_xch_elems(const Geometry &g) {   // 8-byte words per frame
-    const int lpp = g.D / 16, cols = kPairWaves * (64 / lpp);
-    return (size_t)((g.w + cols - 1) / cols) * g.h * lpp * 5;
-}
-
-void launch_pair_sweep(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTable &slabs, unsigned long long *xch, uint32_t *ticket, uint32_t *status,
-                       const Geometry &g, uint32_t epoch, int dy, int out_path, int sink_path, int n_frames, hipStream_t s) {
-    const int lpp = g.D / 16, cols = kPairWaves * (64 / lpp);
-    PairArgs a{cen_l, cen_r, slabs, xch, ticket, status, g, epoch, out_path, sink_path, (g.w + cols - 1) / cols};
-    dim3 grid(a.nblk * n_frames), block(64 * (kPairWaves + 1));
-    if (dy > 0) {
-        switch (g.D) {
-            case 64: hipLaunchKernelGGL((pair_sweep_kernel<4, 1>), grid, block, 0, s, a); break;
-            case 128: hipLaunchKernelGGL((pair_sweep_kernel<8, 1>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((pair_sweep_kernel<16, 1>), grid, block, 0, s, a); break;
-        }
-    } else {
-        switch (g.D) {
-            case 64: hipLaunchKernelGGL((pair_sweep_kernel<4, -1>), grid, block, 0, s, a); break;
-            case 128: hipLaunchKernelGGL((pair_sweep_kernel<8, -1>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((pair_sweep_kernel<16, -1>), grid, block, 0, s, a); break;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ winner takes all
 // Block = 64 pixels of one row; a pixel is owned by LPP = D/16 lanes, 16 disparities per lane as 8
 // packed u16 pairs.  Per path one 16-byte non-temporal load per lane, the
@@ -1260,13 +1021,8 @@ void uniq_table_host(float u, uint16_t *out) {
     for (int i = 0; i < 2048; ++i) out[i] = (uint16_t)uniq_threshold((uint32_t)i, u);
 }
 
-// PAIRS (launch plan PAIRS): the slabs of paths 0 and 1 hold the penalty parts of TWO paths each (pair_sweep_kernel),
-// slabs 4 and 7 do not exist; the 4*C those four paths share is recomputed here from the census planes -- the tile's
-// right-census window is staged in LDS once per block, a lane reads its 16 features from there (the kernel is bound by
-// the slab reads: the ~50 extra VALU operations per lane and pass are free).
 struct WtaArgs {
     SlabTable slabs;
-    const uint32_t *cen_l, *cen_r;   // PAIRS only
     uint16_t *wta_l;
     uint32_t *right_pk;
     Geometry g;
@@ -1281,7 +1037,7 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 
 // TOP2 = the S5 variant (CART_OPT_SPEC_S5_TOP2): uniqueness looks at the SECOND-best (cost, d) only -- the second-smallest
 // (cost << 16 | d) key of the pixel -- instead of at every disparity.
-template <int LPP, bool PAIRS, bool TOP2 = false>
+template <int LPP, bool TOP2 = false>
 __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_lds[];  // [kWtaTileX][DP]
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -1300,13 +1056,7 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
     // the 256 threads at D = 64 -- was over half of this kernel's VALU instructions and made the D = 64 variant VALU-bound.)
     __shared__ uint32_t s_rv[kWtaTileX + D];
     for (int i = threadIdx.x; i < kWtaTileX + D; i += 256) s_rv[i] = 0xffffffffu;
-    __shared__ uint32_t s_cen[PAIRS ? kWtaTileX + D : 1];   // right features of columns x0 - min_disp - (D-1) .. x0 + 63 - min_disp
-    if constexpr (!PAIRS) __syncthreads();
-    if constexpr (PAIRS) {
-        const uint32_t *crow = a.cen_r + (size_t)frame * g.census_elems + (size_t)y * g.cpitch + g.cpadl + x0 - g.min_disp - (D - 1);
-        for (int i = threadIdx.x; i < kWtaTileX + D - 1; i += 256) s_cen[i] = crow[i];   // left of the image: zero padding (oracle S3)
-        __syncthreads();
-    }
+    __syncthreads();
 
     uint32_t pk_res[NPASS], tot_res[NPASS], thr_res[NPASS];   // TOP2: tot_res holds the pixel's second-smallest key
     constexpr bool PREFETCH = NPASS >= 4;
@@ -1355,18 +1105,6 @@ __global__ __launch_bounds__(256) void wta_kernel(WtaArgs a) {
                     sm[q] += v[q] & 0x00ff00ffu;
                     sm[4 + q] += perm(0u, v[q], 0x0c030c01u);
                 }
-            }
-        }
-        if constexpr (PAIRS) {
-            // C(d) = popcount(left feature ^ right feature at x - min_disp - d); window index of d: xl + D-1 - d
-            const uint32_t fl = a.cen_l[(size_t)frame * g.census_elems + (size_t)y * g.cpitch + g.cpadl + xc];
-            const uint32_t *wp = s_cen + (min(x0 + xl, g.w - 1) - x0) + D - 1 - d0;   // d0 -> wp[0], d0 + j -> wp[-j]
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t ca = (uint32_t)__builtin_popcount(fl ^ wp[-2 * q]) | ((uint32_t)__builtin_popcount(fl ^ wp[-2 * q - 1]) << 16);
-                const uint32_t cb = (uint32_t)__builtin_popcount(fl ^ wp[-8 - 2 * q]) | ((uint32_t)__builtin_popcount(fl ^ wp[-9 - 2 * q]) << 16);
-                sm[q] += ca << 2;       // 4 * C: halves stay below 2^16 (sums <= 8 * 255)
-                sm[4 + q] += cb << 2;
             }
         }
         v4u *dst = reinterpret_cast<v4u *>(s_lds + xl * DP + d0);  // LDS tile in natural disparity order
@@ -1461,32 +1199,19 @@ void launch_wta(const SlabTable &slabs, uint16_t *wta_l, uint32_t *right_pk, con
                 int n_frames, hipStream_t s, bool top2) {
     dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
     const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
-    WtaArgs a{slabs, nullptr, nullptr, wta_l, right_pk, g, thr, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
+    WtaArgs a{slabs, wta_l, right_pk, g, thr, g.P, {0, 1, 2, 3, 4, 5, 6, 7}};
     if (top2) {   // S5 variant (CART_OPT_SPEC_S5_TOP2)
         switch (g.D) {
-            case 64: hipLaunchKernelGGL((wta_kernel<4, false, true>), grid, block, lds, s, a); break;
-            case 128: hipLaunchKernelGGL((wta_kernel<8, false, true>), grid, block, lds, s, a); break;
-            default: hipLaunchKernelGGL((wta_kernel<16, false, true>), grid, block, lds, s, a); break;
+            case 64: hipLaunchKernelGGL((wta_kernel<4, true>), grid, block, lds, s, a); break;
+            case 128: hipLaunchKernelGGL((wta_kernel<8, true>), grid, block, lds, s, a); break;
+            default: hipLaunchKernelGGL((wta_kernel<16, true>), grid, block, lds, s, a); break;
         }
         return;
     }
     switch (g.D) {
-        case 64: hipLaunchKernelGGL((wta_kernel<4, false>), grid, block, lds, s, a); break;
-        case 128: hipLaunchKernelGGL((wta_kernel<8, false>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((wta_kernel<16, false>), grid, block, lds, s, a); break;
-    }
-}
-
-// plan PAIRS: slabs 0 / 1 = pair sums {down, down-right} / {up, up-right}, slabs 2, 3, 5, 6 = right, left, down-left, up-left
-void launch_wta_pairs(const SlabTable &slabs, const uint32_t *cen_l, const uint32_t *cen_r, uint16_t *wta_l, uint32_t *right_pk,
-                      const Geometry &g, const uint16_t *thr, int n_frames, hipStream_t s) {
-    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);
-    const size_t lds = (size_t)kWtaTileX * (g.D + 8) * sizeof(uint16_t);
-    WtaArgs a{slabs, cen_l, cen_r, wta_l, right_pk, g, thr, 6, {0, 1, 2, 3, 5, 6, 0, 0}};
-    switch (g.D) {
-        case 64: hipLaunchKernelGGL((wta_kernel<4, true>), grid, block, lds, s, a); break;
-        case 128: hipLaunchKernelGGL((wta_kernel<8, true>), grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL((wta_kernel<16, true>), grid, block, lds, s, a); break;
+        case 64: hipLaunchKernelGGL(wta_kernel<4>, grid, block, lds, s, a); break;
+        case 128: hipLaunchKernelGGL(wta_kernel<8>, grid, block, lds, s, a); break;
+        default: hipLaunchKernelGGL(wta_kernel<16>, grid, block, lds, s, a); break;
     }
 }
 

@@ -3,11 +3,13 @@
 // the C ABI (disparity -> plane derivative + per-frame histogram), the histograms are all-gathered, every GPU replays the
 // plane-parameter schedule of DisparityPlaneSegmentationModule::updatePlaneParameters (planeseg.cu:379-403) for the whole
 // sequence and classifies its own frames, and disparity + planes come back to GPU 0 in sequence order.
-// Transport: RCCL (ncclCommInitAll, one communicator per GPU and purpose).  Scatter and gather are grouped ncclSend / ncclRecv,
+// Transport: RCCL (ncclCommInitAll, ONE communicator per GPU).  Scatter and gather are grouped ncclSend / ncclRecv,
 // ONE per peer and image kind (GPU 0 packs a peer's frames into a staging area first) -- GPU 0 has a direct xGMI link to every
 // peer, so no ring is involved -- the histogram exchange is one ncclAllGather (1 KB per frame).
-// Sequences are double-buffered: every GPU has a copy stream beside its compute stream, submit(i+1) posts the scatter of
-// sequence i+1, then the gather of sequence i, then the kernels of i+1, so that the transfers run beside the kernels.
+// Sequences are double-buffered: every GPU has a copy stream beside its compute stream; EVERY RCCL operation is enqueued on the
+// copy stream (so a GPU never has collectives of two communicators, or of one communicator on two streams, in flight), ordered
+// against the kernels by events: submit(i+1) posts the scatter of sequence i+1, then the all-gather, classification and gather of
+// sequence i, then the disparity kernels of i+1 -- the transfers run beside the kernels (order table in sharder.cpp).
 // The reference has no multi-GPU mode (include/cartslam.hpp:4 is frame pipelining on one GPU): this is new functionality.
 // The same sharding over torch.distributed lives in cartslam/pipeline.py and must give identical results.
 #pragma once
@@ -52,15 +54,22 @@ class FrameSharder {
     void wait(double timeoutSeconds = 120.0);
     // submit + wait
     void processSequence(const uint8_t *left, const uint8_t *right, int nFrames, int16_t *disparity, uint8_t *planes);
+    // What has been enqueued so far: sequences finished (all-gather + classification + gather posted), grouped RCCL operations (three per
+    // sequence: scatter, all-gather, gather), hipStreamWaitEvent calls (per sequence 1 + 4 per GPU, + 1 per GPU from the third sequence on).
+    // Pipelined and one-at-a-time use issue the same operations in a different interleaving; the counts must agree (cart_shard_amd checks).
+    struct Counters { long long sequences = 0, collectiveGroups = 0, streamWaits = 0; };
+    Counters counters() const { return counters_; }
 
    private:
     struct Rank;
-    struct Pending { int nFrames = 0; int16_t *disparity = nullptr; uint8_t *planes = nullptr; int buf = 0; bool live = false; };
-    void postGather(const Pending &p);
+    struct Pending { int nFrames = 0, firstId = 1; int16_t *disparity = nullptr; uint8_t *planes = nullptr; int buf = 0; bool live = false; };
+    void finish(const Pending &p);
+    void streamWait(void *stream, void *event);
+    Counters counters_;
     std::vector<std::unique_ptr<Rank>> ranks;
     const int framesPerGpu, width, height;
     int nextId = 1;
     long long submitted = 0;
-    Pending pending;   // kernels enqueued, gather not yet posted
+    Pending pending;   // disparity kernels enqueued; all-gather, classification and gather not yet posted
 };
 }  // namespace cart

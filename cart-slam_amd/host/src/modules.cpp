@@ -93,11 +93,13 @@ EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
     // Opt-in (CARTSLAM_PLACEMENT_TRIES > 1): pick the fastest of a few physical placements of the cost-slab workspace (include/cart_engine.h,
     // cart_engine_tune_placement: the aggregation launch runs 8-9 % faster on some).  Not fatal: a failed probe leaves the first placement.
     if (params.num_disparities > 0 && placementTries() > 1) {
-        float first = 0.f, kept = 0.f;
-        if (cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), /*max_extra_bytes: default cap*/ 0, &first, &kept) != 0)
+        cart_placement_report rep;
+        static const char *const modes[] = {"unknown", "fast", "slow", "box-slow"};
+        if (cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), /*max_extra_bytes: default cap*/ 0, &rep) != 0)
             std::fprintf(stderr, "[cartslam_amd] placement tuning failed (%s); keeping the first placement\n", cart_last_error(engine));
         else
-            std::fprintf(stderr, "[cartslam_amd] placement tuning: launch pair %.3f -> %.3f ms\n", first, kept);
+            std::fprintf(stderr, "[cartslam_amd] placement tuning: launch pair %.3f -> %.3f ms, %d placements timed in %.2f s, mode %s\n", rep.ms_first, rep.ms_kept,
+                         rep.candidates, rep.seconds, modes[rep.mode & 3]);
     }
 }
 EngineHandle::~EngineHandle() { cart_engine_destroy(engine); }

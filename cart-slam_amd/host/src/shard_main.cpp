@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
         std::vector<int16_t> hd(npx * n), hd0;
         std::vector<uint8_t> hp(npx * n), hp0;
         double pairsPerSecond[2] = {0, 0};
+        cart::FrameSharder::Counters counted[2];
         for (int pass = 0; pass < 2; ++pass) {   // fresh sharder per pass: frame ids (and the cumulative histogram) start over
             cart::FrameSharder sharder(devices, p, (perCall + gpus - 1) / gpus, ui, ri);
             if (hipSetDevice(0) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
@@ -60,6 +61,7 @@ int main(int argc, char **argv) {
                 else sharder.submit(dl + f0 * npx, dr + f0 * npx, cnt, dd + f0 * npx, dp + f0 * npx);
             }
             sharder.wait();
+            counted[pass] = sharder.counters();
             pairsPerSecond[pass] = n / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             (void)hipSetDevice(0);
             (void)hipMemcpy(hd.data(), dd, npx * n * 2, hipMemcpyDeviceToHost);
@@ -71,10 +73,19 @@ int main(int argc, char **argv) {
             std::cerr << "fatal: the pipelined pass differs from the one-call-at-a-time pass\n";
             return 2;
         }
+        // the two passes enqueue the same operations in a different interleaving: three grouped RCCL operations per sequence, all on one
+        // communicator and one stream per GPU, and the same number of stream waits
+        if (counted[0].sequences != counted[1].sequences || counted[0].collectiveGroups != counted[1].collectiveGroups || counted[0].streamWaits != counted[1].streamWaits ||
+            counted[1].collectiveGroups != 3 * counted[1].sequences) {
+            std::cerr << "fatal: the pipelined pass enqueued other operations than the one-call-at-a-time pass (" << counted[1].collectiveGroups << " / "
+                      << counted[0].collectiveGroups << " RCCL groups, " << counted[1].streamWaits << " / " << counted[0].streamWaits << " stream waits)\n";
+            return 2;
+        }
         std::ofstream(out + "/disparity.bin", std::ios::binary).write(reinterpret_cast<const char *>(hd.data()), (std::streamsize)(npx * n * 2));
         std::ofstream(out + "/planes.bin", std::ios::binary).write(reinterpret_cast<const char *>(hp.data()), (std::streamsize)(npx * n));
         std::cout << "frames " << n << " gpus " << gpus << " frames_per_call " << perCall << " pairs_per_s " << pairsPerSecond[1]
-                  << " pairs_per_s_one_call_at_a_time " << pairsPerSecond[0] << "\n";
+                  << " pairs_per_s_one_call_at_a_time " << pairsPerSecond[0] << " sequences " << counted[1].sequences << " rccl_groups " << counted[1].collectiveGroups
+                  << " stream_waits " << counted[1].streamWaits << " communicators_per_gpu 1\n";
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "fatal: " << e.what() << "\n";

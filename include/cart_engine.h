@@ -71,15 +71,8 @@ void cart_engine_destroy(cart_engine *engine);
  *   FUSED_UP  the "up" path is computed inside the WTA sweep and never stored (2*(P-1)*D bytes / pixel).
  * AUTO picks per launch from the measured table in DESIGN.md section 4.  Options are plain integers so that the
  * boundary stays C; nothing in the engine reads the environment.
- *
- * EXPERIMENTAL, measured and lost (kept as a tested, bit-exact option because it is the measurement
- * that closed the question -- AUTO never picks it and no module adapter uses it):
- *   PAIRS     (8 paths) {down, down-right} and {up, up-right} each ride on one sweep over the image rows and leave ONE u8
- *             slab holding the sum of their penalty parts: 6 slabs instead of 8 (2*6*D bytes / pixel); the WTA adds the
- *             shared 4*C back from the census planes.  Needs 2*p2 <= 255 and w*h*D < ~2^30 (32-bit lane offsets of the
- *             sweep's sink slab); other engines fall back to FUSED_UP.  3.9-4.1 ms per 16 pairs at 16, 32 and 48 frames per
- *             launch against 3.0 for SLABS (profiles/r03_stageA.txt). */
-enum { CART_PLAN_AUTO = -1, CART_PLAN_SLABS = 0, CART_PLAN_FUSED_UP = 1, CART_PLAN_PAIRS = 2 };
+ */
+enum { CART_PLAN_AUTO = -1, CART_PLAN_SLABS = 0, CART_PLAN_FUSED_UP = 1 };
 enum {
     CART_OPT_PLAN = 0,            /* CART_PLAN_*; default AUTO */
     CART_OPT_PLAN_MIN_FRAMES = 1, /* with a forced plan: launches of fewer frames take SLABS (default 1) */
@@ -99,18 +92,10 @@ int cart_engine_get_option(cart_engine *engine, int option, int *value);
  * path slabs that plan materialises (bench.py prices its roofline line from this instead of re-deriving it). */
 typedef struct {
     int frames_per_launch;
-    int plan;             /* CART_PLAN_SLABS | FUSED_UP | PAIRS */
+    int plan;             /* CART_PLAN_SLABS | FUSED_UP */
     int slabs_written;    /* u8 slabs of D bytes per pixel written (and read once) per frame */
 } cart_launch_plan;
 int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_plan *out);
-
-/* Synchronises the device, returns the engine's device status word and CLEARS it (0 = healthy), so a report covers the
- * calls made since the previous query.  Bit 0: a pair sweep (plan PAIRS) gave up waiting for the hand-over of its left
- * neighbour block (bounded poll, so that a grid always drains); the disparities of those calls are then invalid.  It
- * cannot happen on a healthy device and only a caller that forces CART_PLAN_PAIRS can see it: such a caller asks here
- * after its stream synchronise (the Python driver's Engine.device_status(); the soak tool and the PAIRS tests do).  The
- * module adapters never force a plan and need not ask. */
-int cart_engine_device_status(cart_engine *engine, unsigned *status);
 
 /* Placement tuning of the cost-slab workspace (no reference counterpart; OPTIONAL and opt-in: nothing calls it unless the caller asks).
  * On MI355X the time of the two slab-bound launches depends on WHICH physical memory backs the slabs: the same kernels run in one of two
@@ -120,17 +105,32 @@ int cart_engine_device_status(cart_engine *engine, unsigned *status);
  * of at most 8 GiB - 64 MiB).
  * The call works per UNIT = the slot groups behind slots [k n, (k+1) n) of an `n_frames` call (n = min(n_frames, frames per launch)),
  * for the first (at most four) such ranges: it times the aggregation + WTA launches of n frames on the unit's current allocations, then on
- * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others; it stops early once the kept set is 13 % faster
- * than the slowest one seen (i.e. is a fast one) or after 0.25 s per allowed try + 1 s per 20 GB of workspace.
+ * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others.  A unit's search stops (cart_placement_report::stop_reason)
+ *   FAST_FOUND  once the kept set is 13 % faster than the slowest one seen, i.e. is a fast one;
+ *   BOX_SLOW    once six sets have been timed and the fastest is within 5 % of the slowest: this box has no fast placement to offer
+ *               (about one fresh box in ten; 64 tries bought 1.4 % on such a box) -- the best seen is kept, set-up stays under 2 s;
+ *   TRIES / TIME / MEMORY  out of tries, out of the unit's time share ((0.25 s per allowed try + 1 s per 20 GB of workspace) / units),
+ *               or no room for another candidate.
+ * `mode` says what unit 0 -- where a caller with one call in flight lives -- ended on: FAST, SLOW (search ran out on a set that is not a fast
+ * one), BOX_SLOW, or UNKNOWN (one try: nothing to compare with).  A reader of a bench line can so tell a slow box from a regression.
  * TRANSIENT FOOTPRINT: candidates that lost stay allocated while the search goes on (freed at once, the allocator would hand the same
  * pages back); at no time does the call hold more than `max_extra_bytes` beyond the engine's own workspace -- 0 selects two units' worth
  * (one unit = the groups of one n-frame call: 7.6 GB at 1242x375 D=128 P=8 with n = 16), SIZE_MAX lifts the cap (the search then stops
- * when the next candidate would not leave 4 GiB of device memory free: what bench.py uses, reported as `placement_tuning`).  With a
- * cap below one unit the call measures and returns without trying anything.  Peak device memory of the process during the call =
- * workspace + min(max_extra_bytes, (max_tries - 1) x unit); after it, the workspace alone.
- * The engine must be idle; results do not change (every placement gives the same bits).  ms_first / ms_kept (may be NULL): mean
- * launch-pair time over the probed units before and after.  About 16 ms per try at 1242x375 D=128 P=8. */
-int cart_engine_tune_placement(cart_engine *engine, int n_frames, int max_tries, size_t max_extra_bytes, float *ms_first, float *ms_kept);
+ * when the next candidate would not leave 4 GiB of device memory free; that check is not atomic across processes: pass a finite cap when
+ * several processes share a GPU).  With a cap below one unit the call measures and returns without trying anything.  Peak device memory
+ * of the process during the call = workspace + min(max_extra_bytes, (max_tries - 1) x unit); after it, the workspace alone.
+ * The engine must be idle; results do not change (every placement gives the same bits).  `report` may be NULL. */
+enum { CART_PLACE_MODE_UNKNOWN = 0, CART_PLACE_MODE_FAST = 1, CART_PLACE_MODE_SLOW = 2, CART_PLACE_MODE_BOX_SLOW = 3 };
+enum { CART_PLACE_STOP_NOTHING_TO_DO = 0, CART_PLACE_STOP_FAST_FOUND = 1, CART_PLACE_STOP_BOX_SLOW = 2, CART_PLACE_STOP_TRIES = 3,
+       CART_PLACE_STOP_TIME = 4, CART_PLACE_STOP_MEMORY = 5 };
+typedef struct {
+    float ms_first, ms_kept;                 /* launch-pair time (aggregation + WTA of n frames), mean over the probed units, before / after */
+    float ms_fastest_seen, ms_slowest_seen;  /* unit 0: the kept placement and the slowest one timed */
+    float seconds;                           /* wall time of the call */
+    int units, candidates;                   /* units probed; placements timed in all (the initial ones included) */
+    int mode, stop_reason;                   /* CART_PLACE_MODE_* / CART_PLACE_STOP_* of unit 0 */
+} cart_placement_report;
+int cart_engine_tune_placement(cart_engine *engine, int n_frames, int max_tries, size_t max_extra_bytes, cart_placement_report *report);
 
 /* Message of the last failed call made by THIS thread on `engine` (or of a failed
  * create when engine == NULL).  Never NULL. */

@@ -23,7 +23,7 @@ for line in open(summary):
     if m and kernel:
         vals.setdefault(kernel, {})[m.group(1)] = float(m.group(2))
 suffix = "" if plan == "slabs" else "_" + plan
-slabs = {"slabs": P, "fused_up": P - 1, "pairs": 6}[plan]
+slabs = {"slabs": P, "fused_up": P - 1}[plan]
 for k, v in vals.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue

@@ -25,7 +25,7 @@ while time.time() - t0 < budget:
     uniq = rng.choice((0, 1, 5, 12, 12, 12, 15, 30, 50, 99, 100))
     radius = rng.choice((-1, -1, 1, 2, 2, 3, 5, 8)); iters = rng.randint(1, 5)
     variants = rng.choice((0, 0, 0, 1, 2, 4, 3, 5, 6, 7))
-    plan = rng.choice(("auto", "auto", "slabs", "fused_up", "pairs"))
+    plan = rng.choice(("auto", "auto", "slabs", "fused_up"))
     B = rng.choice((1, 1, 2, 3, 5, 8)) if not big else rng.choice((1, 2))
     chunk = rng.choice((0, 0, 0, 1, 2, 3))
     ch = rng.choice((1, 1, 3)); scene = rng.choice(synth.SCENES); s = rng.randint(0, 1 << 30)
@@ -67,10 +67,9 @@ while time.time() - t0 < budget:
     ep = O.classify(eb, pp); eids, en = O.ccl(ep)
     diff += int((pd.cpu().numpy() != eb).sum()) + int((hist.cpu().numpy() != eh).sum()) + int((planes.cpu().numpy() != ep).sum()) + \
             int((ids.cpu().numpy() != eids).sum()) + int(int(n.item()) != en)
-    status = eng.device_status()
     eng.close()
     cases += 1; frames += B
-    print(f"{cases:4d} {desc}: valid {float((exp0 != -32768).mean()):.3f} components {en} differing values {diff} status {status}", flush=True)
+    print(f"{cases:4d} {desc}: valid {float((exp0 != -32768).mean()):.3f} components {en} differing values {diff}", flush=True)
     if diff:
         print("FAILED: " + desc); sys.exit(1)
 print(f"parity fuzz: seed {seed}, {cases} cases, {frames} frames, 0 differing values, {time.time() - t0:.0f} s")

@@ -33,6 +33,8 @@ def test_struct_layouts_match_header():
     from cartslam import _lib
     assert C.sizeof(_lib.EngineParams) == 12 * 4 and C.sizeof(_lib.PlaneParams) == 6 * 4
     assert C.sizeof(_lib.SuperpixelParams) == 6 * 8
+    assert C.sizeof(_lib.PlacementReport) == 5 * 4 + 4 * 4 and C.sizeof(_lib.LaunchPlan) == 3 * 4   # cart_placement_report, cart_launch_plan
+    assert len(_lib.PLACE_MODES) == 4 and len(_lib.PLACE_STOPS) == 6                                   # CART_PLACE_MODE_* / CART_PLACE_STOP_*
     sp = _lib.SuperpixelParams()
     _lib.load().cart_superpixel_default_params(C.byref(sp))
     # cartconfig.cpp:128-133
