@@ -282,8 +282,8 @@ def run(args, world, rank, dev_index):
                      "launch_pair_ms_first": round(rep["ms_first"], 4), "launch_pair_ms_kept": round(rep["ms_kept"], 4),
                      "launch_pair_ms_slowest_seen": round(rep["ms_slowest_seen"], 4), "seconds": round(rep["seconds"], 3),
                      "what": "cart_engine_tune_placement: aggregation + WTA launch of one batch on fresh physical placements of the slab workspace, fastest "
-                             "kept (set-up, outside every timed region).  mode: fast = the kept set is >= 13 % under the slowest seen (both launches in "
-                             "their fast modes); slow = the search ran out first; box-slow = six sets within 5 % of each other, this box has no fast "
+                             "kept (set-up, outside every timed region).  mode: fast = the kept set is >= 5.5 % under the slowest seen (both launches in "
+                             "their fast modes); slow = the search ran out first; box-slow = six sets within 4 % of each other, this box has no fast "
                              "placement (its aggregation launch then runs ~7 % longer: a slow box, not a regression)"}
         placement["value_untuned"] = round(untuned, 2)
 

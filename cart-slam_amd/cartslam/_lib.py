@@ -76,6 +76,7 @@ PROTOTYPES = {
     "cart_plane_classify_multi": (_i, [_vp, _i, _vp, _sz, C.POINTER(PlaneParams), _i, _vp, _sz, _vp]),
     "cart_plane_ccl": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp]),
     "cart_plane_ccl_stats": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _i, _vp, _vp]),
+    "cart_plane_ccl_table": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _i, _vp, _vp]),
     "cart_plane_schedule_create": (_i, [_vp, _i, C.POINTER(PlaneParams), _i, _i, C.POINTER(_vp)]),
     "cart_plane_schedule_destroy": (None, [_vp]),
     "cart_plane_schedule_advance": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "cart_find_peaks": (_i, [C.POINTER(C.c_int32), _i] + [C.POINTER(C.c_int)] * 4),
     "cart_debug_read": (_i, [_vp, _i, _i, _vp, _sz]),
     "cart_debug_uniq_table": (_i, [_vp, _i, C.POINTER(C.c_uint16)]),
+    "cart_debug_ccl_scratch_nonzero": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "cart_debug_slab_layout": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "cart_engine_set_timing": (_i, [_vp, _i]),
     "cart_engine_collect_timing": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i, C.POINTER(_i)]),

@@ -345,7 +345,25 @@ class Engine:
                                                    C.c_void_p(ncomp.data_ptr()), _stream_ptr()), "cart_plane_ccl_stats")
         return table, ncomp
 
+    def plane_ccl_table(self, planes, max_components=4096):
+        """plane_ccl + plane_ccl_stats in one call (cart_plane_ccl_table: four launches) -> (ids, table, n_components)."""
+        import torch
+        n, p, s, fs = _geom(planes, 1)
+        ids = torch.empty(planes.shape, dtype=torch.int32, device=planes.device)
+        _, ip, is_, ifs = _geom(ids, 1)
+        table = torch.empty((n, max_components, 7), dtype=torch.int32, device=planes.device)  # rows >= n_components stay undefined
+        ncomp = torch.empty((n,), dtype=torch.int32, device=planes.device)
+        self._check(self._lib.cart_plane_ccl_table(self._h, n, p, s, fs, ip, is_, ifs, C.c_void_p(table.data_ptr()), int(max_components),
+                                                   C.c_void_p(ncomp.data_ptr()), _stream_ptr()), "cart_plane_ccl_table")
+        return ids, table, ncomp
+
     # ---- diagnostics ----
+    def debug_ccl_scratch_nonzero(self):
+        """Non-zero words of the component-table scratch (must be 0 between calls)."""
+        n = C.c_size_t(0)
+        self._check(self._lib.cart_debug_ccl_scratch_nonzero(self._h, C.byref(n)), "cart_debug_ccl_scratch_nonzero")
+        return n.value
+
     def debug_read(self, what, frame_slot=0):
         lib = self._lib
         npx = self.width * self.height

@@ -425,8 +425,7 @@ class StereoPipeline:
         if kept is not None:
             out["hists"] = kept
         if self.with_ccl and n:
-            out["ids"], out["n_components"] = eng.plane_ccl(planes)
-            out["components"], _ = eng.plane_ccl_stats(planes, out["ids"], self.max_components)
+            out["ids"], out["components"], out["n_components"] = eng.plane_ccl_table(planes, self.max_components)
         elif self.with_ccl:   # a rank without frames still hands every key to the gather
             out["ids"] = torch.empty((0, eng.height, eng.width), dtype=torch.int32, device=dev)
             out["n_components"] = torch.empty((0,), dtype=torch.int32, device=dev)

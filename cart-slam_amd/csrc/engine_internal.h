@@ -98,7 +98,11 @@ void launch_wta_fused(const uint32_t *cen_l, const uint32_t *cen_r, const SlabTa
 void launch_uniq_table(float u, uint16_t *out_dev, hipStream_t s);   // test access to the integer uniqueness threshold
 void uniq_table_host(float u, uint16_t *out);
 void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames, hipStream_t s,
-                 int spec = 0);   // spec: CART_OPT_SPEC_* bits (1 = S8 zero-disparity-invalid, 2 = S7 replicated border)
+                 int spec = 0);
+// post stage + first Jacobi pass of the radius-2 interpolation in one launch (sgm_kernels.hip, post_interp_kernel)
+bool post_interp_fusable(int radius, int min_disp16, int max_disp);
+void launch_post_interp(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames,
+                        hipStream_t s, int spec, int min_disp16, int max_disp);   // spec: CART_OPT_SPEC_* bits (1 = S8 zero-disparity-invalid, 2 = S7 replicated border)
 
 // ---- launchers (post_kernels.hip) ----
 void launch_interpolate(const int16_t *src, size_t src_step, size_t src_fs, const OutBatch &dst, int w, int h, int radius,
@@ -115,12 +119,15 @@ struct ClassifyParams { cart_plane_params p[kMaxBatchArgs]; };
 void launch_classify(const int16_t *deriv, size_t step, size_t fs, const ClassifyParams &params, int per_frame,
                      uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s,
                      const FrameTable *deriv_table = nullptr, const FrameTable *planes_table = nullptr);
+// stat / seg / table non-null: ids + count + component table in four launches (stat = [n_frames][npx][5] scratch, all zero between calls;
+// seg = [n_frames][h][tile columns] roots per row segment); null: ids + count in three
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
-                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
-
-// component table (S12): rowwork = [n_frames][h] int32, slot = [n_frames][npx] int32 (only root positions are written/read)
-void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *rowwork,
-                      int32_t *slot, cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
+                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s, int32_t *stat = nullptr, int32_t *seg = nullptr,
+                cart_component *table = nullptr, int max_components = 0);
+// component table (S12) of a given id map
+void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *stat, int32_t *seg,
+                      cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s);
+size_t ccl_stats_ws_ints(int w, int h);   // int32 elements of the table workspace per slot: scratch + segment counts
 
 void launch_classify_dev(const int16_t *deriv, size_t step, size_t fs, const cart_plane_params *params_dev, int params_stride,
                          uint8_t *planes, size_t pstep, size_t pfs, int w, int h, int n_frames, hipStream_t s);

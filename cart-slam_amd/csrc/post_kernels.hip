@@ -483,10 +483,12 @@ __device__ __forceinline__ int lds_find(const int *P, int i) {
     return i;
 }
 
-__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int w, int h, size_t npx) {
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ncomp_zero, int w, int h,
+                                                       size_t npx) {
     __shared__ uint8_t cls[CT_TH][CT_TW];
     __shared__ int parent[CT_TH * CT_TW];
     const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH, frame = blockIdx.z;
+    if (ncomp_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ncomp_zero[frame] = 0;   // ccl_final_kernel<false> counts into it two launches later
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int x = x0 + lane;
     // 1. classes + runs of the wave's rows
@@ -572,21 +574,79 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t *planes, 
     (void)ncols;
 }
 
+// ---- component statistics, accumulated where the ids are made -------------------------------------------------------------
+// The component table (oracle S12: id, label, area, bbox, ascending id) used to take four more launches over the finished id
+// map (roots per row, row scan, ordered rank of every root, statistics).  Now the tile that writes a piece of a component adds the
+// piece to that component's SCRATCH entry, keyed by the component's root pixel (a per-tile LDS hash first merges the pieces of a
+// tile: a road-sized component otherwise receives thousands of same-address global atomics per frame), and notes how many roots
+// each of its rows holds (seg[y][tile column]).  ccl_table_kernel then ranks the roots in raster order from those counts alone
+// -- no pass over the id map: it only opens the 64-pixel segments that hold a root -- moves every root's scratch entry into its
+// table row and ZEROES the entry again.  The scratch ([slot][npx] x 5 ints, zero-neutral encoding: area, w - x0, h - y0, x1 + 1,
+// y1 + 1, every field grown by atomicAdd / atomicMax from 0) is therefore all zeros between calls: no memset, no initialised table.
+constexpr int kCclStatInts = 5;
+constexpr int kCclHash = 512;
+struct CclHash { int key[kCclHash], area[kCclHash], x0[kCclHash], y0[kCclHash], x1[kCclHash], y1[kCclHash]; };
+
+__device__ __forceinline__ void ccl_hash_clear(CclHash &hsh, int tid, int w, int h) {
+    for (int i = tid; i < kCclHash; i += 256) { hsh.key[i] = -1; hsh.area[i] = 0; hsh.x0[i] = w; hsh.y0[i] = h; hsh.x1[i] = -1; hsh.y1[i] = -1; }
+}
+__device__ __forceinline__ void ccl_stat_add(int32_t *stat, int root, int area, int x0, int y0, int x1, int y1, int w, int h) {
+    int32_t *e = stat + (size_t)root * kCclStatInts;
+    atomicAdd(&e[0], area);
+    atomicMax(&e[1], w - x0); atomicMax(&e[2], h - y0);
+    atomicMax(&e[3], x1 + 1); atomicMax(&e[4], y1 + 1);
+}
+// one row of a tile, one wave: `id` = the lane's final id (-1: no component) at (x, y).  Counts the row's roots into *seg_out and adds the row's
+// pieces (maximal runs of one id inside the wave) to the tile's hash, or straight to the scratch when the hash is full.
+__device__ __forceinline__ void ccl_row_stats(CclHash &hsh, int32_t *stat, int32_t *seg_out, int id, int x, int y, int lane, int w, int h) {
+    const unsigned long long rootm = __ballot(id >= 0 && id == y * w + x);
+    if (lane == 0) *seg_out = __popcll(rootm);
+    const int idp = __shfl_up(id, 1);
+    const bool in = id >= 0;
+    const bool head = in && (lane == 0 || idp != id);
+    const unsigned long long heads = __ballot(head), ins = __ballot(in);
+    if (!head) return;
+    const unsigned long long later = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    const unsigned long long stop = (heads | ~ins) & later;   // next head or first non-member lane
+    const int end_lane = stop ? __ffsll((long long)stop) - 2 : 63;
+    const int len = end_lane - lane + 1;
+    int hpos = (int)(((unsigned)id * 2654435761u) >> 23);   // 9 bits
+    for (int probe = 0; probe < 8; ++probe, hpos = (hpos + 1) & (kCclHash - 1)) {
+        const int old = atomicCAS(&hsh.key[hpos], -1, id);
+        if (old == -1 || old == id) {
+            atomicAdd(&hsh.area[hpos], len);
+            atomicMin(&hsh.x0[hpos], x); atomicMax(&hsh.x1[hpos], x + len - 1);
+            atomicMin(&hsh.y0[hpos], y); atomicMax(&hsh.y1[hpos], y);
+            return;
+        }
+    }
+    ccl_stat_add(stat, id, len, x, y, x + len - 1, y, w, h);
+}
+__device__ __forceinline__ void ccl_hash_flush(const CclHash &hsh, int32_t *stat, int tid, int w, int h) {
+    for (int i = tid; i < kCclHash; i += 256)
+        if (hsh.key[i] >= 0) ccl_stat_add(stat, hsh.key[i], hsh.area[i], hsh.x0[i], hsh.y0[i], hsh.x1[i], hsh.y1[i], w, h);
+}
+
 // Final ids, again one workgroup per 64 x 32 tile.  After the border unions a pixel's link is either inside its tile (an
 // ordinary pixel pointing at its tile root, or a tile root that a union hung under another root of the same tile) or it
 // is a tile root: a link to itself or to a root outside the tile.  Tile roots walk the global forest once and park the
 // result in LDS; everybody else follows its in-tile links through an LDS copy of the tile's links until it meets a
 // resolved entry (one or two hops).  No per-pixel gathers from global memory, no separate compression pass.
-__global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int32_t *ncomp, int w,
-                                                        int h, size_t npx) {
+// STATS: the tile also feeds the component table (see above); the count then comes from ccl_table_kernel, not from here.
+template <bool STATS>
+__global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int32_t *ncomp, int32_t *stat_all,
+                                                        int32_t *seg_all, int w, int h, size_t npx) {
     __shared__ int link[CT_TH * CT_TW];      // local index of the pixel's link target, -1 unlabelled, -2 resolved in root_of
     __shared__ int root_of[CT_TH * CT_TW];
     __shared__ int roots;
+    __shared__ typename std::conditional<STATS, CclHash, int>::type hsh_mem;   // the tile's component hash exists only with STATS
+    CclHash &hsh = reinterpret_cast<CclHash &>(hsh_mem);
     const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH, frame = blockIdx.z;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int x = x0 + lane;
     const int32_t *L = work + (size_t)frame * npx;
     if (threadIdx.x == 0) roots = 0;
+    if constexpr (STATS) ccl_hash_clear(hsh, threadIdx.x, w, h);
 #pragma unroll
     for (int k = 0; k < CT_TH / 4; ++k) {
         const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;
@@ -610,184 +670,155 @@ __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int
     }
     __syncthreads();
     int found = 0;
+    const int ntx = gridDim.x;
 #pragma unroll
     for (int k = 0; k < CT_TH / 4; ++k) {
-        const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;
-        if (x >= w || y >= h) continue;
+        const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;   // y is wave-uniform
+        if (y >= h) continue;
         int id = -1;
-        int cur = li, lk = link[li];
-        if (lk != -1) {
-            while (lk >= 0) { cur = lk; lk = link[cur]; }   // in-tile links only ever lead to smaller indices: terminates at a resolved entry
-            id = root_of[cur];
+        if (x < w) {
+            int cur = li, lk = link[li];
+            if (lk != -1) {
+                while (lk >= 0) { cur = lk; lk = link[cur]; }   // in-tile links only ever lead to smaller indices: terminates at a resolved entry
+                id = root_of[cur];
+            }
+            row_ptr(ids, ifs, istep, frame, y)[x] = id;
+            found += id == y * w + x;
         }
-        row_ptr(ids, ifs, istep, frame, y)[x] = id;
-        found += id == y * w + x;
+        if constexpr (STATS)
+            ccl_row_stats(hsh, stat_all + (size_t)frame * npx * kCclStatInts, seg_all + ((size_t)frame * h + y) * ntx + blockIdx.x, id, x, y, lane, w, h);
     }
-    if (ncomp) {   // components = pixels that are their own root; one global atomic per workgroup (noise scenes have ~10^4 roots per
-                   // frame, and that many same-address atomics took longer than the labelling)
+    if constexpr (STATS) {
+        __syncthreads();
+        ccl_hash_flush(hsh, stat_all + (size_t)frame * npx * kCclStatInts, threadIdx.x, w, h);
+    } else if (ncomp) {   // components = pixels that are their own root; one global atomic per workgroup (noise scenes have ~10^4 roots per
+                          // frame, and that many same-address atomics took longer than the labelling); ccl_tile_kernel zeroed the counter
         if (found) atomicAdd(&roots, found);
         __syncthreads();
         if (threadIdx.x == 0 && roots) atomicAdd(&ncomp[frame], roots);
     }
 }
 
+// The statistics half alone, for a caller that hands in an id map (cart_plane_ccl_stats): same tiles, ids read instead of resolved.
+// An id that is not a root of the map it comes from (ids[id] != id: not an id map of cart_plane_ccl) is skipped -- its scratch entry
+// would never be collected, and the scratch has to return to zero.
+__global__ __launch_bounds__(256) void ccl_stats_tile_kernel(const int32_t *ids, size_t istep, size_t ifs, int32_t *stat_all, int32_t *seg_all, int w,
+                                                             int h, size_t npx) {
+    __shared__ CclHash hsh;
+    const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH, frame = blockIdx.z;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int x = x0 + lane, ntx = gridDim.x;
+    ccl_hash_clear(hsh, threadIdx.x, w, h);
+    __syncthreads();
+    int32_t *stat = stat_all + (size_t)frame * npx * kCclStatInts;
+#pragma unroll
+    for (int k = 0; k < CT_TH / 4; ++k) {
+        const int y = y0 + wid * (CT_TH / 4) + k;
+        if (y >= h) continue;
+        int id = x < w ? row_ptr(ids, ifs, istep, frame, y)[x] : -1;
+        if (id >= 0) {
+            const bool ok = (size_t)id < npx && row_ptr(ids, ifs, istep, frame, id / w)[id - (id / w) * w] == id;
+            if (!ok) id = -1;
+        }
+        ccl_row_stats(hsh, stat, seg_all + ((size_t)frame * h + y) * ntx + blockIdx.x, id, x, y, lane, w, h);
+    }
+    __syncthreads();
+    ccl_hash_flush(hsh, stat, threadIdx.x, w, h);
+}
+
+// Roots are the pixels whose id is their own linear index, so raster order = ascending id = table order.  One workgroup per band of 32 rows
+// (a tile row) and frame: roots before the band and per row of the band from seg[][] (a few thousand ints per frame), then each wave walks its
+// rows segment by segment, opens the segments that hold a root, ranks the roots by ballot, writes their table rows from the scratch entries and
+// zeroes those.  The band that ends the image writes the frame's component count.
+__global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs,
+                                                        int32_t *stat_all, const int32_t *seg_all, cart_component *table, int max_components,
+                                                        int32_t *ncomp, int w, int h, int ntx, size_t npx) {
+    __shared__ int red[4];
+    __shared__ int rowbase[CT_TH + 1];
+    const int band = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int y0 = band * CT_TH, rows = min(CT_TH, h - y0);
+    const int32_t *seg = seg_all + (size_t)frame * h * ntx;
+    int before = 0;
+    for (int i = tid; i < y0 * ntx; i += 256) before += seg[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if (lane == 0) red[wid] = before;
+    if (tid < CT_TH) {
+        int s = 0;
+        if (tid < rows)
+            for (int t = 0; t < ntx; ++t) s += seg[(size_t)(y0 + tid) * ntx + t];
+        rowbase[tid + 1] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = red[0] + red[1] + red[2] + red[3];
+        rowbase[0] = run;
+        for (int r = 0; r < CT_TH; ++r) { run += rowbase[r + 1]; rowbase[r + 1] = run; }   // rowbase[r] = roots before row y0 + r
+        if (ncomp && y0 + rows >= h) ncomp[frame] = run;
+    }
+    __syncthreads();
+    int32_t *stat = stat_all + (size_t)frame * npx * kCclStatInts;
+    cart_component *tab = table + (size_t)frame * max_components;
+    for (int r = wid; r < rows; r += 4) {   // wave-uniform
+        const int y = y0 + r;
+        if (rowbase[r + 1] == rowbase[r]) continue;
+        int run = rowbase[r];
+        const int32_t *irow = row_ptr(ids, ifs, istep, frame, y);
+        const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
+        for (int t = 0; t < ntx; ++t) {
+            const int cnt = seg[(size_t)y * ntx + t];
+            if (cnt == 0) continue;
+            const int x = t * CT_TW + lane;
+            const bool root = x < w && irow[x] == y * w + x;
+            const unsigned long long m = __ballot(root);
+            if (root) {
+                const int rk = run + __popcll(m & ((1ull << lane) - 1ull));
+                int32_t *e = stat + (size_t)(y * w + x) * kCclStatInts;
+                const int area = e[0], ex0 = e[1], ey0 = e[2], ex1 = e[3], ey1 = e[4];
+                e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; e[4] = 0;
+                if (rk < max_components) {
+                    cart_component c;
+                    c.id = y * w + x; c.label = prow[x]; c.area = area; c.x0 = w - ex0; c.y0 = h - ey0; c.x1 = ex1 - 1; c.y1 = ey1 - 1;
+                    tab[rk] = c;
+                }
+            }
+            run += cnt;
+        }
+    }
+}
+
+// ids + count: three launches (the tile kernel zeroes the counter).  With `table`: the final kernel also feeds the component scratch and
+// ccl_table_kernel writes table and count -- four launches for ids, count and table, none of them a memset.
 void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, int32_t *ids, size_t istep, size_t ifs,
-                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
+                int32_t *ncomp, int w, int h, int n_frames, hipStream_t s, int32_t *stat, int32_t *seg, cart_component *table, int max_components) {
     const size_t npx = (size_t)w * h;
-    if (ncomp) (void)hipMemsetAsync(ncomp, 0, sizeof(int32_t) * (size_t)n_frames, s);
     const int ntx = (w + CT_TW - 1) / CT_TW, nty = (h + CT_TH - 1) / CT_TH;
-    hipLaunchKernelGGL(ccl_tile_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx);
+    hipLaunchKernelGGL(ccl_tile_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, table ? nullptr : ncomp, w, h, npx);
     const int nrows = nty - 1, ncols = ntx - 1;   // inner tile borders
     if (nrows + ncols > 0) {
         const int span = std::max(nrows > 0 ? w : 0, ncols > 0 ? h : 0);
         hipLaunchKernelGGL(ccl_border_kernel, dim3((span + 255) / 256, nrows + ncols, n_frames), dim3(256), 0, s, planes, pstep, pfs, work, w, h, npx, nrows, ncols);
     }
-    hipLaunchKernelGGL(ccl_final_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, w, h, npx);
-}
-
-// ------------------------------------------------------------------ component table (oracle S12: id, label, area, bbox)
-// Roots are the pixels whose id is their own linear index, so raster order = ascending id.  (1) roots per row,
-// (2) exclusive scan over the rows (one block per frame), (3) ordered rank of every root -> slot[root] and the
-// initialised table row, (4) every 64-pixel piece of a horizontal run adds its length / extent to its component's row
-// with a handful of atomics (pieces come from one wave ballot, no serial walks).
-__global__ __launch_bounds__(256) void ccl_root_count_kernel(const int32_t *ids, size_t istep, size_t ifs, int32_t *rowcount, int w, int h) {
-    __shared__ int tot[4];
-    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
-    const int32_t *row = row_ptr(ids, ifs, istep, frame, y);
-    int c = 0;
-    for (int x = tid; x < w; x += 256) c += row[x] == y * w + x;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((tid & 63) == 0) tot[tid >> 6] = c;
-    __syncthreads();
-    if (tid == 0) rowcount[(size_t)frame * h + y] = tot[0] + tot[1] + tot[2] + tot[3];
-}
-
-__global__ __launch_bounds__(256) void ccl_root_scan_kernel(int32_t *rowcount, int32_t *ncomp, int h) {  // in place: counts -> exclusive bases
-    __shared__ int part[256];
-    const int frame = blockIdx.x, tid = threadIdx.x;
-    int32_t *rc = rowcount + (size_t)frame * h;
-    const int per = (h + 255) / 256, y0 = tid * per, y1 = min(y0 + per, h);
-    int s = 0;
-    for (int y = y0; y < y1; ++y) s += rc[y];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        if (ncomp) ncomp[frame] = run;
-    }
-    __syncthreads();
-    int run = part[tid];
-    for (int y = y0; y < y1; ++y) { const int v = rc[y]; rc[y] = run; run += v; }
-}
-
-__global__ __launch_bounds__(256) void ccl_root_init_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep,
-                                                            size_t ifs, const int32_t *rowbase, int32_t *slot, cart_component *table,
-                                                            int max_components, int w, int h, size_t npx) {
-    __shared__ int wave_tot[4];
-    const int y = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int32_t *row = row_ptr(ids, ifs, istep, frame, y);
-    const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
-    int carry = rowbase[(size_t)frame * h + y];
-    for (int x0 = 0; x0 < w; x0 += 256) {
-        const int x = x0 + tid;
-        const bool root = x < w && row[x] == y * w + x;
-        const unsigned long long m = __ballot(root);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wid] = __popcll(m);
-        __syncthreads();
-        int prefix = carry, all = carry;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < wid) prefix += wave_tot[k];
-            all += wave_tot[k];
-        }
-        if (root) {
-            const int r = prefix + before;
-            slot[(size_t)frame * npx + (size_t)y * w + x] = r;
-            if (r < max_components) {
-                cart_component c;
-                c.id = y * w + x; c.label = prow[x]; c.area = 0; c.x0 = w; c.y0 = h; c.x1 = -1; c.y1 = -1;
-                table[(size_t)frame * max_components + r] = c;
-            }
-        }
-        carry = all;
-        __syncthreads();
+    if (table) {
+        hipLaunchKernelGGL(ccl_final_kernel<true>, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, (int32_t *)nullptr, stat, seg, w, h, npx);
+        hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, (const int32_t *)ids, istep, ifs, stat, (const int32_t *)seg, table,
+                           max_components, ncomp, w, h, ntx, npx);
+    } else {
+        hipLaunchKernelGGL(ccl_final_kernel<false>, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, (int32_t *)nullptr,
+                           (int32_t *)nullptr, w, h, npx);
     }
 }
 
-// One block per 64 x 64 tile (the 4 waves interleave its rows).  The pieces of the tile are first merged per component in
-// an LDS hash; one set of global atomics per (tile, component) remains -- a road-sized component otherwise receives
-// thousands of same-address global atomics per frame, which serialise in L2 (1 ms per 16-frame batch with one atomic set
-// per piece; whole-height stripes have too few blocks: 107 us).  A full hash falls back to direct atomics.
-__global__ __launch_bounds__(256) void ccl_stats_accum_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep,
-                                                              size_t ifs, const int32_t *slot, cart_component *table, int max_components,
-                                                              int w, int h, size_t npx) {
-    constexpr int HS = 512;
-    __shared__ int hkey[HS], harea[HS], hx0[HS], hy0[HS], hx1[HS], hy1[HS];
-    constexpr int TR = 64;   // tile rows
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, frame = blockIdx.z;
-    for (int i = tid; i < HS; i += 256) { hkey[i] = -1; harea[i] = 0; hx0[i] = w; hy0[i] = h; hx1[i] = -1; hy1[i] = -1; }
-    __syncthreads();
-    const int x = blockIdx.x * 64 + lane;
-    cart_component *tab = table + (size_t)frame * max_components;
-    const int yend = min((int)(blockIdx.y + 1) * TR, h);
-    for (int y = blockIdx.y * TR + wid; y < yend; y += 4) {   // wave-uniform
-        const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
-        const int c = x < w ? prow[x] : 255;
-        const bool in = c <= 1;
-        const int cp = __shfl_up(c, 1);
-        const bool head = in && (lane == 0 || cp != c);   // a piece starts at lane 0 of the wave or where the label changes
-        const unsigned long long heads = __ballot(head), ins = __ballot(in);
-        if (head) {
-            const unsigned long long later = lane == 63 ? 0ull : (~0ull << (lane + 1));
-            const unsigned long long stop = (heads | ~ins) & later;   // next head or first non-member lane
-            const int end_lane = stop ? __ffsll((long long)stop) - 2 : 63;
-            const int len = end_lane - lane + 1;
-            const int id = row_ptr(ids, ifs, istep, frame, y)[x];
-            const int r = slot[(size_t)frame * npx + id];
-            if (r < max_components) {
-                int hpos = (int)(((unsigned)r * 2654435761u) >> 23);   // 9 bits
-                bool done = false;
-                for (int probe = 0; probe < 8 && !done; ++probe, hpos = (hpos + 1) & (HS - 1)) {
-                    const int old = atomicCAS(&hkey[hpos], -1, r);
-                    if (old == -1 || old == r) {
-                        atomicAdd(&harea[hpos], len);
-                        atomicMin(&hx0[hpos], x); atomicMax(&hx1[hpos], x + len - 1);
-                        atomicMin(&hy0[hpos], y); atomicMax(&hy1[hpos], y);
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    cart_component *e = tab + r;
-                    atomicAdd(&e->area, len);
-                    atomicMin(&e->x0, x); atomicMax(&e->x1, x + len - 1);
-                    atomicMin(&e->y0, y); atomicMax(&e->y1, y);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < HS; i += 256)
-        if (hkey[i] >= 0) {
-            cart_component *e = tab + hkey[i];
-            atomicAdd(&e->area, harea[i]);
-            atomicMin(&e->x0, hx0[i]); atomicMax(&e->x1, hx1[i]);
-            atomicMin(&e->y0, hy0[i]); atomicMax(&e->y1, hy1[i]);
-        }
-}
-
-void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *rowwork,
-                      int32_t *slot, cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
+// component table of a given id map: two launches
+void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs, int32_t *stat, int32_t *seg,
+                      cart_component *table, int max_components, int32_t *ncomp, int w, int h, int n_frames, hipStream_t s) {
     const size_t npx = (size_t)w * h;
-    hipLaunchKernelGGL(ccl_root_count_kernel, dim3(h, n_frames), dim3(256), 0, s, ids, istep, ifs, rowwork, w, h);
-    hipLaunchKernelGGL(ccl_root_scan_kernel, dim3(n_frames), dim3(256), 0, s, rowwork, ncomp, h);
-    hipLaunchKernelGGL(ccl_root_init_kernel, dim3(h, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs, (const int32_t *)rowwork, slot,
-                       table, max_components, w, h, npx);
-    hipLaunchKernelGGL(ccl_stats_accum_kernel, dim3((w + 63) / 64, (h + 63) / 64, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs,
-                       (const int32_t *)slot, table, max_components, w, h, npx);
+    const int ntx = (w + CT_TW - 1) / CT_TW, nty = (h + CT_TH - 1) / CT_TH;
+    hipLaunchKernelGGL(ccl_stats_tile_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, ids, istep, ifs, stat, seg, w, h, npx);
+    hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs, stat, (const int32_t *)seg, table, max_components,
+                       ncomp, w, h, ntx, npx);
 }
+size_t ccl_stats_ws_ints(int w, int h) { return (size_t)w * h * kCclStatInts + (size_t)h * ((w + CT_TW - 1) / CT_TW); }
 
 // ------------------------------------------------------------------ narrow copy (downloads over PCIe)
 // A device -> host-mapped copy for the module outputs a caller wants in host memory.  hipMemcpyAsync(D2H) runs here as
@@ -812,6 +843,6 @@ void launch_narrow_copy(const void *src, void *dst, size_t bytes, int blocks, hi
     hipLaunchKernelGGL(narrow_copy_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), bytes);
 }
 
-int kernel_count() { return 58; }  // device kernels in the library (counted from the generated ISA): sgm_kernels 29 (census, aggregate x6, wta x6, wta_fused x8, rv_merge x6, post, uniq_table) + post_kernels 18 + superpixel_kernels 8 + flow 3
+int kernel_count() { return 58; }  // device kernels in the library (counted from the generated ISA): sgm_kernels 30 (census, aggregate x6, wta x6, wta_fused x8, rv_merge x6, post, post_interp, uniq_table) + post_kernels 17 + superpixel_kernels 8 + flow 3
 
 }  // namespace cart_amd

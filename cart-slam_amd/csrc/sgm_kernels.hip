@@ -1698,15 +1698,10 @@ __device__ __forceinline__ uint32_t left_median_at(const uint16_t *img, int x, i
 // One pixel per thread: the right-view median is a gather at x - d, so the launch wants as many independent threads as
 // it can get (four pixels per thread with shared left columns measured 50 % slower).
 // spec: bit 0 = S8 variant (integer disparity 0 is invalid too), bit 1 = S7 variant (replicated-border medians); 0 = oracle S7 / S8
-__global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const uint32_t *right_pk,
-                                                   const uint8_t *gray_l, OutBatch out, Geometry g, int spec) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
-    if (x >= g.w || y >= g.h) return;
-    const uint16_t *wl = wta_l + (size_t)frame * g.npx;
-    const uint32_t *rp = right_pk + (size_t)frame * g.npx;
+__device__ __forceinline__ int post_value(const uint16_t *wl, const uint32_t *rp, const uint8_t *gray, int x, int y, const Geometry &g, int spec) {
     const bool replicate = (spec & 2) != 0;
     const uint32_t ml = left_median_at(wl, x, y, g.w, g.h, replicate);
-    bool invalid = gray_l[(size_t)frame * g.npx + (size_t)y * g.w + x] == 0 || ml == kWtaInvalid || ((spec & 1) && (ml >> 4) == 0);
+    bool invalid = gray[(size_t)y * g.w + x] == 0 || ml == kWtaInvalid || ((spec & 1) && (ml >> 4) == 0);
     if (!invalid) {
         const int d = (int)(ml >> 4);
         const int k = x - d;
@@ -1715,9 +1710,77 @@ __global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const 
             if (abs(mr - d) > 1) invalid = true;
         }
     }
-    const int v = invalid ? (g.min_disp - 1) * 16 : (int)ml + g.min_disp * 16;
+    return invalid ? (g.min_disp - 1) * 16 : (int)ml + g.min_disp * 16;
+}
+
+__global__ __launch_bounds__(256) void post_kernel(const uint16_t *wta_l, const uint32_t *right_pk,
+                                                   const uint8_t *gray_l, OutBatch out, Geometry g, int spec) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, frame = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const int v = post_value(wta_l + (size_t)frame * g.npx, right_pk + (size_t)frame * g.npx, gray_l + (size_t)frame * g.npx, x, y, g, spec);
     uint8_t *obase = out.scattered ? reinterpret_cast<uint8_t *>(out.frames[frame]) : reinterpret_cast<uint8_t *>(out.ptr) + (size_t)frame * out.frame_stride;
     reinterpret_cast<int16_t *>(obase + (size_t)y * out.step)[x] = (int16_t)v;
+}
+
+// post_kernel + the first Jacobi pass of disparity::interpolate at radius 2 (interpolateKernel, interpolation.cu:17-82: the 3 x 3 window mean of
+// the values inside (min_disp16, max_disp), count > r*r + 1 -- post_kernels.hip, interpolate_r2_kernel) in one launch: a workgroup computes the post
+// values of its 64 x 16 tile and a one-pixel halo into LDS (66 x 18: 16 % more post work) and smooths from there, so the intermediate image is never
+// written and the step has one launch less.  Out-of-image halo cells hold a value below every valid range (skipped like the reference's
+// out-of-image taps).  Same bits as the two launches (tests: every disparity comparison with smoothing_radius = 2).
+constexpr int PI_W = 64, PI_H = 16, PI_LW = PI_W + 2, PI_LH = PI_H + 2, PI_PITCH = 68;
+__global__ __launch_bounds__(256) void post_interp_kernel(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, OutBatch out, Geometry g,
+                                                          int spec, int min_disp16, int max_disp) {
+    __shared__ int16_t tile[PI_LH][PI_PITCH];
+    const int x0 = blockIdx.x * PI_W, y0 = blockIdx.y * PI_H, frame = blockIdx.z, tid = threadIdx.x;
+    const uint16_t *wl = wta_l + (size_t)frame * g.npx;
+    const uint32_t *rp = right_pk + (size_t)frame * g.npx;
+    const uint8_t *gray = gray_l + (size_t)frame * g.npx;
+    for (int i = tid; i < PI_LH * PI_LW; i += 256) {
+        const int ty = i / PI_LW, tx = i - ty * PI_LW;
+        const int x = x0 - 1 + tx, y = y0 - 1 + ty;
+        int v = -32768;   // outside the image: never inside (min_disp16, max_disp) -- min_disp16 >= 0
+        if (x >= 0 && x < g.w && y >= 0 && y < g.h) v = post_value(wl, rp, gray, x, y, g, spec);
+        tile[ty][tx] = (int16_t)v;
+    }
+    __syncthreads();
+    // thread -> 4 adjacent pixels of one row: tile columns 4 q + 1 .. 4 q + 4 of tile row r + 1
+    const int q = tid & 15, r = tid >> 4;
+    const int xb = x0 + 4 * q, y = y0 + r;
+    if (xb >= g.w || y >= g.h) return;
+    int csum[6], ccnt[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { csum[c] = 0; ccnt[c] = 0; }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int v = tile[r + l][4 * q + c];
+            if (v > min_disp16 && v < max_disp) { csum[c] += v; ++ccnt[c]; }
+        }
+    }
+    uint8_t *obase = out.scattered ? reinterpret_cast<uint8_t *>(out.frames[frame]) : reinterpret_cast<uint8_t *>(out.ptr) + (size_t)frame * out.frame_stride;
+    int16_t *orow = reinterpret_cast<int16_t *>(obase + (size_t)y * out.step);
+    int16_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sum = csum[i] + csum[i + 1] + csum[i + 2], count = ccnt[i] + ccnt[i + 1] + ccnt[i + 2];
+        o[i] = count > 5 ? (int16_t)(int)((float)sum / (float)count) : (int16_t)CART_DISPARITY_INVALID;   // interpolation.cu:33: count > r*r + 1 = 5
+    }
+    if (((reinterpret_cast<uintptr_t>(orow) | out.step) & 7) == 0 && xb + 4 <= g.w) {
+        *reinterpret_cast<uint2 *>(orow + xb) = make_uint2((uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (xb + i < g.w) orow[xb + i] = o[i];
+    }
+}
+
+// can the post stage take the first interpolation pass with it?  (radius 2, the range test representable in the tile's s16 sentinel scheme)
+bool post_interp_fusable(int radius, int min_disp16, int max_disp) { return radius == 2 && min_disp16 >= 0 && min_disp16 < (1 << 15) && max_disp > min_disp16; }
+void launch_post_interp(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g, int n_frames,
+                        hipStream_t s, int spec, int min_disp16, int max_disp) {
+    dim3 grid((g.w + PI_W - 1) / PI_W, (g.h + PI_H - 1) / PI_H, n_frames), block(256);
+    hipLaunchKernelGGL(post_interp_kernel, grid, block, 0, s, wta_l, right_pk, gray_l, out, g, spec, min_disp16, max_disp);
 }
 
 void launch_post(const uint16_t *wta_l, const uint32_t *right_pk, const uint8_t *gray_l, const OutBatch &out, const Geometry &g,

@@ -381,17 +381,16 @@ system_data_t DisparityPlaneSegmentationModule::runInternal(System &system, Syst
     std::shared_ptr<image_t> components, componentTable, componentCount;
     if (labelComponents) {
         components = std::make_shared<image_t>(disparity->rows, disparity->cols, CV_32SC1);
-        if (cart_plane_ccl(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0, nullptr, stream.s) != 0)
-            eng->fail("cart_plane_ccl");
         componentTable = std::make_shared<image_t>(CARTSLAM_PLANE_COMPONENT_TABLE_ROWS, 7, CV_32SC1);
         componentCount = std::make_shared<image_t>(1, 1, CV_32SC1);
         static_assert(sizeof(cart_component) == 7 * sizeof(int32_t), "table rows are 7 x int32");
         if (componentTable->step != 7 * sizeof(int32_t)) {  // DeviceImage pads rows to 256 B: the table wants tight rows
             componentTable = std::make_shared<image_t>(1, CARTSLAM_PLANE_COMPONENT_TABLE_ROWS * 7, CV_32SC1);
         }
-        if (cart_plane_ccl_stats(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0,
+        // ids, count and table in one call: the pass that writes the final ids also gathers the component statistics (four launches)
+        if (cart_plane_ccl_table(eng->get(), 1, planes->ptr<uint8_t>(), planes->step, 0, components->ptr<int32_t>(), components->step, 0,
                                  componentTable->ptr<cart_component>(), CARTSLAM_PLANE_COMPONENT_TABLE_ROWS, componentCount->ptr<int32_t>(), stream.s) != 0)
-            eng->fail("cart_plane_ccl_stats");
+            eng->fail("cart_plane_ccl_table");
     }
     stream.wait();
     system_data_t out;

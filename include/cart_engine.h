@@ -106,13 +106,14 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * The call works per UNIT = the slot groups behind slots [k n, (k+1) n) of an `n_frames` call (n = min(n_frames, frames per launch)),
  * for the first (at most four) such ranges: it times the aggregation + WTA launches of n frames on the unit's current allocations, then on
  * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others.  A unit's search stops (cart_placement_report::stop_reason)
- *   FAST_FOUND  once the kept set is 13 % faster than the slowest one seen, i.e. is a fast one;
- *   BOX_SLOW    once six sets have been timed and the fastest is within 5 % of the slowest: this box has no fast placement to offer
+ *   FAST_FOUND  once the kept set is 10 % faster than the slowest one seen, i.e. is a fast one;
+ *   BOX_SLOW    once six sets have been timed and the fastest is within 4 % of the slowest: this box has no fast placement to offer
  *               (about one fresh box in ten; 64 tries bought 1.4 % on such a box) -- the best seen is kept, set-up stays under 2 s;
  *   TRIES / TIME / MEMORY  out of tries, out of the unit's time share ((0.25 s per allowed try + 1 s per 20 GB of workspace) / units),
  *               or no room for another candidate.
- * `mode` says what unit 0 -- where a caller with one call in flight lives -- ended on: FAST, SLOW (search ran out on a set that is not a fast
- * one), BOX_SLOW, or UNKNOWN (one try: nothing to compare with).  A reader of a bench line can so tell a slow box from a regression.
+ * `mode` says what unit 0 -- where a caller with one call in flight lives -- ended on: FAST (kept set at least 5.5 % under the slowest seen),
+ * SLOW (the search ran out on a set that is not), BOX_SLOW, or UNKNOWN (one try: nothing to compare with).  The ratios hold for a probe on a
+ * warmed-up GPU (call it after a few real calls, as bench.py does; straight after engine creation the levels lie 12-13 % apart).  A reader of a bench line can so tell a slow box from a regression.
  * TRANSIENT FOOTPRINT: candidates that lost stay allocated while the search goes on (freed at once, the allocator would hand the same
  * pages back); at no time does the call hold more than `max_extra_bytes` beyond the engine's own workspace -- 0 selects two units' worth
  * (one unit = the groups of one n-frame call: 7.6 GB at 1242x375 D=128 P=8 with n = 16), SIZE_MAX lifts the cap (the search then stops
@@ -233,6 +234,13 @@ typedef struct cart_component {
 int cart_plane_ccl_stats(cart_engine *engine, int n_frames,
                          const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
                          const int32_t *ids, size_t ids_step, size_t ids_frame_stride,
+                         cart_component *table, int max_components, int32_t *n_components, void *stream);
+/* cart_plane_ccl + cart_plane_ccl_stats in one call (same ids, count and table): the pass that writes the final ids also gathers
+ * the component statistics, four launches in all instead of three + two.  `ids` must be an id map made by cart_plane_ccl /
+ * cart_plane_ccl_table for cart_plane_ccl_stats to describe it: ids that are not roots of their own map are ignored there. */
+int cart_plane_ccl_table(cart_engine *engine, int n_frames,
+                         const uint8_t *planes, size_t planes_step, size_t planes_frame_stride,
+                         int32_t *ids, size_t ids_step, size_t ids_frame_stride,
                          cart_component *table, int max_components, int32_t *n_components, void *stream);
 
 /* replaces: HistogramPeakPlaneParameterProvider::updatePlaneParameters (planeseg.cu:405-458) +
@@ -370,6 +378,10 @@ int cart_debug_uniq_table(cart_engine *engine, int uniqueness_ratio, uint16_t *o
 /* Test / diagnostic access to the layout of the cost-slab workspace: the slots are cut into groups, each group one
  * device allocation of at most 8 GiB - 64 MiB.  Any pointer may be NULL.  group_bytes: bytes of a full group (the last one may be smaller). */
 int cart_debug_slab_layout(cart_engine *engine, int *group_slots, int *n_groups, size_t *slot_bytes, size_t *group_bytes);
+/* Test access: synchronises and counts the non-zero words of the component-table scratch (every table call must hand it back all
+ * zeros: cart_plane_ccl_table / cart_plane_ccl_stats collect exactly what they accumulated).  *nonzero = 0 also when no table call
+ * has allocated the scratch yet. */
+int cart_debug_ccl_scratch_nonzero(cart_engine *engine, size_t *nonzero);
 
 /* Per-stage device time (hipEvents recorded on the caller's stream around each stage of
  * cart_compute_disparity[_batch]).  set_timing(1) enables recording and clears the record ring

@@ -931,6 +931,50 @@ def test_ccl_tile_borders(torch_cuda):
 
 
 @pytest.mark.gpu
+def test_ccl_table_in_one_call(torch_cuda):
+    """cart_plane_ccl_table: ids, count and component table from ONE call (the pass that writes the final ids feeds a statistics scratch keyed
+    by root pixel; ccl_table_kernel ranks the roots from per-segment counts and empties the scratch again).  Against the oracle on the tile-border
+    maps, hard shapes and noise; the two-call path (cart_plane_ccl + cart_plane_ccl_stats) must agree; the scratch must be all zeros after
+    every call -- also after a truncated table and after an id map that is not one (foreign ids are ignored, not accumulated for ever)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(515)
+    for w, h in [(64, 32), (65, 33), (200, 100), (16, 8), (320, 37), (70, 160), (1242, 375)]:
+        eng = make_engine(w, h, 0, 0, inflight=6)
+        yy, xx = np.mgrid[0:h, 0:w]
+        maps = [rng.integers(0, 3, (h, w)).astype(np.uint8), ((xx + yy) % 2).astype(np.uint8), np.zeros((h, w), np.uint8)]
+        for scale in (3, 9, 27):
+            maps.append(np.kron(rng.integers(0, 3, (h // scale + 1, w // scale + 1)), np.ones((scale, scale), int))[:h, :w].astype(np.uint8))
+        cap = w * h + 1
+        pl = dev(torch, np.stack(maps))
+        for rep in range(2):   # the second call runs on the scratch the first one left behind
+            ids, table, n = eng.plane_ccl_table(pl, max_components=cap)
+            assert eng.debug_ccl_scratch_nonzero() == 0, f"{w}x{h}: scratch not returned to zero"
+            for f, m in enumerate(maps):
+                eids, en = O.ccl(m)
+                et, _ = O.ccl_stats(m, eids)
+                assert (ids[f].cpu().numpy() == eids).all() and int(n[f]) == en, f"{w}x{h} map {f} ids / count"
+                got = table[f, :en].cpu().numpy()
+                assert (got == et).all(), f"{w}x{h} map {f}: {int((got != et).any(axis=1).sum())} table rows differ"
+        ids2, n2 = eng.plane_ccl(pl)
+        table2, n3 = eng.plane_ccl_stats(pl, ids2, max_components=cap)
+        assert torch.equal(ids2, ids) and torch.equal(n2, n) and torch.equal(n3, n)
+        for f in range(len(maps)):
+            assert torch.equal(table2[f, :int(n[f])], table[f, :int(n[f])])
+        # truncation: the first rows, the true count, a clean scratch
+        _, ts, ns = eng.plane_ccl_table(pl[:1], max_components=3)
+        et, en = O.ccl_stats(maps[0], O.ccl(maps[0])[0], max_components=3)
+        assert int(ns[0]) == en and (ts[0].cpu().numpy() == et).all() and eng.debug_ccl_scratch_nonzero() == 0
+        # an "id map" whose values are not roots of itself: ignored, nothing left behind, and the next call is right again
+        bogus = torch.full_like(ids2[:1], 5)
+        bogus[0, 0, :8] = -1
+        eng.plane_ccl_stats(pl[:1], bogus, max_components=8)
+        assert eng.debug_ccl_scratch_nonzero() == 0
+        _, t4, n4 = eng.plane_ccl_table(pl[:1], max_components=cap)
+        assert torch.equal(t4[0, :int(n4[0])], table[0, :int(n[0])])
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_full_size_oracle_1080p_d256(torch_cuda):
     """BASELINE configs[3] against the oracle on the full image: 1920x1080, D=256, 8 paths, a batch of 4 (fused WTA, the
     default there) and a single pair (two-kernel WTA), bit for bit; ~2 s of oracle time per pair on the GPU box's cores."""

@@ -145,6 +145,36 @@ def test_kit_passes_on_a_reference_that_agrees(tmp_path):
         check_oracle_against(bad)
 
 
+def _verdict_module():
+    spec = importlib.util.spec_from_file_location("ref_pin_verdict", os.path.join(ROOT, "tools", "ref_pin", "verdict.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_verdict_prints_the_defaults_to_flip(tmp_path):
+    """tools/ref_pin/verdict.py (the last step of run.sh) on fake references: one that needs S8 + S5 flipped names exactly those two
+    cart_engine_set_option lines and exits 3; one that agrees says so and exits 0; one that no setting reproduces exits 4; an empty directory 1."""
+    V = _verdict_module()
+    d = str(tmp_path / "flip")
+    _write_fake_reference(d, variants=5)
+    lines, rc = V.report(V.verdict(d))
+    text = "\n".join(lines)
+    assert rc == 3 and "variant set 5 reproduces the reference bit for bit" in text
+    assert "CART_OPT_SPEC_S8_ZERO_INVALID, 1" in text and "CART_OPT_SPEC_S5_TOP2, 1" in text and "CART_OPT_SPEC_S7_REPLICATE_BORDER" not in text
+    d = str(tmp_path / "agree")
+    _write_fake_reference(d, variants=0)
+    lines, rc = V.report(V.verdict(d))
+    assert rc == 0 and "Nothing to flip" in lines[-1]
+    # a reference that differs in something else (one pixel moved): no setting reproduces it
+    f = os.path.join(d, "ref_disparity_road_160x96_d64_p4_gray.bin")
+    a = np.fromfile(f, np.int16); a[1234] += 16; a.tofile(f)
+    lines, rc = V.report(V.verdict(d))
+    assert rc == 4 and "no setting of S8 / S7 / S5 reproduces the reference" in lines[-1] and "closest: set 0, 1 pixels" in lines[-1]
+    os.makedirs(tmp_path / "empty")
+    assert V.report(V.verdict(str(tmp_path / "empty")))[1] == 1
+
+
 def test_exported_pngs_decode_to_the_golden_inputs(tmp_path):
     """export_inputs.py's PNGs, read back by the repo's own PNG reader (host/src/png.cpp = cv::imread's result: BGR, gray
     replicated), are the golden arrays bit for bit -- gray and BGR -- and cases.txt lists what ref_pin.cpp expects."""
