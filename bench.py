@@ -265,7 +265,7 @@ def run(args, world, rank, dev_index):
     # steps on the placement the engine was created with, after its own pre-warm; informational (`placement_tuning.value_untuned`), never `value`.
     placement = None
     if args.placement_tries > 1:
-        for _ in range(16):
+        for _ in range(32 + args.warmup):   # the same pre-warm + warm-up the timed blocks get
             pipe.process_batch(left, right, inputs_ready=resident)
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -540,7 +540,9 @@ def run(args, world, rank, dev_index):
             "roofline": {"bound": "hbm", "kernel": roof_kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/traffic.json (stored rocprofv3 PMC passes of this configuration: 2 x FETCH_SIZE + WRITE_SIZE), not a counter of this run" if traffic else None,
+                         "traffic_source": "profiles/traffic.json (stored rocprofv3 PMC passes of this configuration: 2 x FETCH_SIZE + WRITE_SIZE), not a counter of this run; bytes that cross the "
+                                           "L2 <-> fabric interface -- reads served by the Infinity Cache included (profiles/r05_census_refetch.txt: at 1920x1080 that is what "
+                                           "the 1.25x over the algorithmic bytes consists of)" if traffic else None,
                          "frac_basis": "SURVEY 8d table bytes: all P slabs written and read once",
                          "alg_bytes_per_launch": agg_bytes, "frames_per_launch": fpl, "launch_ms": round(roof_ms, 4),
                          "launches_timed": ncalls,
