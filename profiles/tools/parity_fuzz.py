@@ -1,7 +1,7 @@
 """Randomised differential campaign, GPU engine against the CPU oracle (test infrastructure, not part of the suite): random image
 sizes (ragged, 16..2048 wide), D, paths, min_disparity, P1 / P2, uniqueness ratio, smoothing radius / iterations, spec variants,
 launch plan, chunking, batch size, gray / BGR, scene family -- whole disparity module of every frame of the batch, then plane
-derivative + histogram + classification + CCL of frame 0.  Time-boxed.   BUDGET_S=600 SEED=1 python profiles/tools/parity_fuzz.py
+derivative + histogram + classification + CCL (every other case with the component table) of frame 0.  Time-boxed.   BUDGET_S=600 SEED=1 python profiles/tools/parity_fuzz.py
 Prints one line per case; exits non-zero on the first differing value (after printing the parameters that reproduce it)."""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -63,8 +63,15 @@ while time.time() - t0 < budget:
     ok, pp = O.histogram_peak_params(eh)
     if not ok:
         pp = (6, 18, -5, 6, 11, 0)
-    planes = eng.plane_classify(pd, pp); ids, n = eng.plane_ccl(planes)
+    planes = eng.plane_classify(pd, pp)
     ep = O.classify(eb, pp); eids, en = O.ccl(ep)
+    if cases % 2:   # ids + count alone (three launches) ...
+        ids, n = eng.plane_ccl(planes)
+    else:           # ... or with the component table from the same pass (cart_plane_ccl_table), whose scratch must come back all zeros
+        cap = rng.choice((en + 1, max(1, en // 2), 4096))
+        ids, table, n = eng.plane_ccl_table(planes, max_components=cap)
+        et, _ = O.ccl_stats(ep, eids, max_components=cap)
+        diff += int((table.cpu().numpy().reshape(-1, 7)[:len(et)] != et).sum()) + int(eng.debug_ccl_scratch_nonzero())
     diff += int((pd.cpu().numpy() != eb).sum()) + int((hist.cpu().numpy() != eh).sum()) + int((planes.cpu().numpy() != ep).sum()) + \
             int((ids.cpu().numpy() != eids).sum()) + int(int(n.item()) != en)
     eng.close()
