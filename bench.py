@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--pcie-copy", default="both", choices=["both", "narrow", "blit"],
                     help="how the PCIe-inclusive leg downloads its outputs (both: time the two ways one after the other and report the faster; they trade places from box to box)")
     ap.add_argument("--pcie-wgs", type=int, default=8, help="workgroups of the narrow download kernel")
+    ap.add_argument("--timing-every", type=int, default=4, help="the engine records its stage events on every n-th step of the timed blocks (1 = every step)")
     ap.add_argument("--chunk", type=int, default=0, help="frames per launch sequence inside a batch (0 = engine default)")
     ap.add_argument("--plan", default="auto", choices=["auto", "slabs", "fused_up"], help="force a launch plan of the SGM core (all bit-identical)")
     args = ap.parse_args()
@@ -283,7 +284,7 @@ def run(args, world, rank, dev_index):
                      "launch_pair_ms_slowest_seen": round(rep["ms_slowest_seen"], 4), "seconds": round(rep["seconds"], 3),
                      "what": "cart_engine_tune_placement: aggregation + WTA launch of one batch on fresh physical placements of the slab workspace, fastest "
                              "kept (set-up, outside every timed region).  mode: fast = the kept set is >= 5.5 % under the slowest seen (both launches in "
-                             "their fast modes); slow = the search ran out first; box-slow = six sets within 4 % of each other, this box has no fast "
+                             "their fast modes); slow = the search ran out first; box-slow = six sets within 1.5 % of each other, this box has no fast "
                              "placement (its aggregation launch then runs ~7 % longer: a slow box, not a regression)"}
         placement["value_untuned"] = round(untuned, 2)
 
@@ -296,7 +297,10 @@ def run(args, world, rank, dev_index):
     for _ in range(args.warmup):
         pipe.process_batch(left, right, inputs_ready=resident)
     torch.cuda.synchronize()
-    eng.set_timing(True)  # hipEvents around each stage, on the stream the kernels are launched on
+    # hipEvents around each stage, on the stream the kernels are launched on, live inside the timed blocks -- on every 4th step: the five
+    # records of a step cost 0.02 ms of its stream time (0.85 % at the headline, 2.3 % at configs[1]: profiles/r04_overlap.txt), and the
+    # launches of one step are the launches of the next (roofline.launches_timed says how many were averaged)
+    eng.set_timing(True, every=args.timing_every)
     # The timed block -- EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks -- is run
     # --repeats times; `value` is the median block (a 20-step block is 60 ms: single blocks differ by a few per cent)
     blocks, last = [], None

@@ -388,8 +388,9 @@ class Engine:
         self._check(self._lib.cart_debug_slab_layout(self._h, C.byref(gs), C.byref(ng), C.byref(sb), C.byref(gb)), "cart_debug_slab_layout")
         return {"group_slots": gs.value, "groups": ng.value, "slot_bytes": sb.value, "group_bytes": gb.value}
 
-    def set_timing(self, enabled=True):
-        self._check(self._lib.cart_engine_set_timing(self._h, 1 if enabled else 0), "cart_engine_set_timing")
+    def set_timing(self, enabled=True, every=1):
+        """Stage events on every `every`-th compute call (every=1: all)."""
+        self._check(self._lib.cart_engine_set_timing(self._h, max(1, int(every)) if enabled else 0), "cart_engine_set_timing")
 
     def collect_timing(self):
         """-> ({stage: mean ms per call}, n_calls) over the calls recorded since set_timing(True)."""

@@ -101,6 +101,8 @@ struct cart_engine {
     int chunk_frames = kLaunchFrames;          // frames per launch sequence inside one batched call
     bool post_only = false;         // no SGM workspaces (num_disparities == 0)
     bool timing = false;
+    int timing_every = 1;           // stage events on every timing_every-th compute call (cart_engine_set_timing)
+    unsigned long long timing_calls = 0;   // compute calls seen while timing is on (guarded by mu)
     std::vector<TimingRec> ring;  // stage events of the last kTimingRing compute calls (guarded by mu)
     size_t ring_calls = 0;
 };
@@ -257,12 +259,13 @@ int dev_alloc(T **p, size_t count) {
 // the range inaccessible; a range re-reserved while other ranges are live did the same) and is gone: nothing in the engine calls
 // hipMemAddressReserve / hipMemMap any more.
 constexpr size_t kSlabChunkBytes = ((size_t)8 << 30) - ((size_t)64 << 20);
-// cart_engine_tune_placement.  The launch pair has a fast and a slow level per placement, 7-9 % apart when the probe runs on a warmed-up GPU
-// with real census planes (2.45-2.48 against 2.6-2.8 ms at the headline: profiles/r05_placement.txt; 12-13 % apart on an idle GPU straight after
-// engine creation, which is where round 4's 0.87 came from).  Stop looking at the first placement kStopRatio under the slowest seen; call the
-// kept one fast when it is kFastRatio under it; after kBoxSlowAfter timed placements that are all within (1 - kBoxSlowRatio) of each other the
-// box has no fast placement to offer.  A candidate replaces the kept set only when it is kSwitchRatio of it or faster (both timed back to back).
-constexpr float kStopRatio = 0.900f, kFastRatio = 0.945f, kBoxSlowRatio = 0.960f, kSwitchRatio = 0.975f;
+// cart_engine_tune_placement.  Each of the two launches has a fast and a slow level per placement: probed on a warmed-up GPU with real census planes the
+// launch pair times at ~2.52-2.57 ms (both fast), ~2.63-2.65 (one slow) or ~2.75-2.78 (both slow) at the headline, and a set re-timed twelve times
+// scatters by 0.4 % (profiles/r05_placement.txt sections 2, 5, 6; on an idle GPU straight after engine creation the extremes lie 12-13 % apart,
+// which is where round 4's 0.87 came from).  A candidate replaces the kept set when it is 1.5 % faster (both timed back to back); the search stops at
+// the first kept set 7 % under the slowest seen (both launches fast against both slow); the kept set is called fast when it is 5.5 % under the
+// slowest seen; after kBoxSlowAfter timed placements that are all within 1.5 % of each other the pool has nothing else to offer.
+constexpr float kStopRatio = 0.930f, kFastRatio = 0.945f, kBoxSlowRatio = 0.985f, kSwitchRatio = 0.985f;
 constexpr int kBoxSlowAfter = 6;
 
 void slab_pool_free(SlabPool &sp) {
@@ -570,11 +573,10 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
         // at most this many bytes beyond the workspace at any time (0 = two units' worth); SIZE_MAX = whatever leaves 4 GiB free
         const size_t cap = max_extra_bytes ? max_extra_bytes : 2 * unit_bytes;
         for (int t = 1; t < max_tries && !mine.empty(); ++t) {
-            // Each launch has a fast and a slow mode (and levels in between): a kept placement 10 % under the slowest pair seen has both launches
-            // in their fast modes -- stop looking.
+            // a kept placement 7 % under the slowest pair seen has both launches in their fast modes -- stop looking
             if (worst_rel * kStopRatio > 1.f) { stop = CART_PLACE_STOP_FAST_FOUND; break; }
             // A process in which no placement is fast (round 4's driver box: 64 candidates between 2.57 and 2.60 ms, 7.7 s of search for 1.4 %): once
-            // kBoxSlowAfter placements have been timed and the slowest is within 4 % of the kept one, there is nothing to find here -- stop.
+            // kBoxSlowAfter placements have been timed and the slowest is within 1.5 % of the kept one, there is nothing to find here -- stop.
             if (seen >= kBoxSlowAfter && worst_rel * kBoxSlowRatio < 1.f) { stop = CART_PLACE_STOP_BOX_SLOW; break; }
             if (seconds_since(t_unit) > unit_budget) { stop = CART_PLACE_STOP_TIME; break; }
             while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
@@ -653,6 +655,8 @@ int cart_engine_set_timing(cart_engine *e, int enabled) {
     for (auto &r : e->ring) r.n = 0;
     e->ring_calls = 0;
     e->timing = enabled != 0;
+    e->timing_every = enabled > 1 ? enabled : 1;
+    e->timing_calls = 0;
     return 0;
 }
 
@@ -734,7 +738,7 @@ int compute_disparity_impl(cart_engine *e, int n_frames, const FrameSet &fr, int
     TimingRec *rec = nullptr;
     if (opt.timing) {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (!e->ring.empty()) { rec = &e->ring[e->ring_calls++ % kTimingRing]; rec->n = 0; }
+        if (!e->ring.empty() && e->timing_calls++ % (unsigned long long)e->timing_every == 0) { rec = &e->ring[e->ring_calls++ % kTimingRing]; rec->n = 0; }
     }
     int nt = 0;
     const int radius = e->params.smoothing_radius, iters = e->params.smoothing_iterations;

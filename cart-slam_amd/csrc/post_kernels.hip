@@ -759,30 +759,53 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
     __syncthreads();
     int32_t *stat = stat_all + (size_t)frame * npx * kCclStatInts;
     cart_component *tab = table + (size_t)frame * max_components;
-    for (int r = wid; r < rows; r += 4) {   // wave-uniform
-        const int y = y0 + r;
-        if (rowbase[r + 1] == rowbase[r]) continue;
-        int run = rowbase[r];
-        const int32_t *irow = row_ptr(ids, ifs, istep, frame, y);
-        const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
-        for (int t = 0; t < ntx; ++t) {
-            const int cnt = seg[(size_t)y * ntx + t];
-            if (cnt == 0) continue;
-            const int x = t * CT_TW + lane;
-            const bool root = x < w && irow[x] == y * w + x;
-            const unsigned long long m = __ballot(root);
-            if (root) {
-                const int rk = run + __popcll(m & ((1ull << lane) - 1ull));
-                int32_t *e = stat + (size_t)(y * w + x) * kCclStatInts;
-                const int area = e[0], ex0 = e[1], ey0 = e[2], ex1 = e[3], ey1 = e[4];
-                e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; e[4] = 0;
-                if (rk < max_components) {
-                    cart_component c;
-                    c.id = y * w + x; c.label = prow[x]; c.area = area; c.x0 = w - ex0; c.y0 = h - ey0; c.x1 = ex1 - 1; c.y1 = ey1 - 1;
-                    tab[rk] = c;
+    // A wave takes rows wid, wid + 4, ...: lane t holds the count of segment c0 + t (all of a row's counts in ONE load; the rows' loads are independent
+    // and in flight together), the segments that hold a root are then walked from a ballot -- a typical label map has a few hundred roots per frame, so most
+    // rows open no segment at all.
+    for (int c0 = 0; c0 < ntx; c0 += 64) {
+        int cnt[CT_TH / 4];
+#pragma unroll
+        for (int k = 0; k < CT_TH / 4; ++k) {
+            const int r = wid + 4 * k;
+            cnt[k] = (r < rows && c0 + lane < ntx) ? seg[(size_t)(y0 + r) * ntx + c0 + lane] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < CT_TH / 4; ++k) {
+            const int r = wid + 4 * k;
+            if (r >= rows) continue;   // wave-uniform
+            const int y = y0 + r;
+            unsigned long long todo = __ballot(cnt[k] > 0);
+            if (!todo && c0 + 64 >= ntx) continue;
+            // roots of this row in the segments before lane t of this chunk (inclusive scan over the lanes, minus the lane's own count)
+            int incl = cnt[k];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int chunk_total = __shfl(incl, 63);
+            const int32_t *irow = row_ptr(ids, ifs, istep, frame, y);
+            const uint8_t *prow = row_ptr(planes, pfs, pstep, frame, y);
+            while (todo) {
+                const int t = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int run = rowbase[r] + __shfl(incl, t) - __shfl(cnt[k], t);   // roots of the image before segment c0 + t of this row
+                const int x = (c0 + t) * CT_TW + lane;
+                const bool root = x < w && irow[x] == y * w + x;
+                const unsigned long long m = __ballot(root);
+                if (root) {
+                    const int rk = run + __popcll(m & ((1ull << lane) - 1ull));
+                    int32_t *e = stat + (size_t)(y * w + x) * kCclStatInts;
+                    const int area = e[0], ex0 = e[1], ey0 = e[2], ex1 = e[3], ey1 = e[4];
+                    e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; e[4] = 0;
+                    if (rk < max_components) {
+                        cart_component c;
+                        c.id = y * w + x; c.label = prow[x]; c.area = area; c.x0 = w - ex0; c.y0 = h - ey0; c.x1 = ex1 - 1; c.y1 = ey1 - 1;
+                        tab[rk] = c;
+                    }
                 }
             }
-            run += cnt;
+            if (lane == 0) rowbase[r] += chunk_total;   // the next chunk of 64 segments of this row continues from here (rows of a wave are its own)
         }
     }
 }

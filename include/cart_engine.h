@@ -105,9 +105,10 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * of at most 8 GiB - 64 MiB).
  * The call works per UNIT = the slot groups behind slots [k n, (k+1) n) of an `n_frames` call (n = min(n_frames, frames per launch)),
  * for the first (at most four) such ranges: it times the aggregation + WTA launches of n frames on the unit's current allocations, then on
- * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others.  A unit's search stops (cart_placement_report::stop_reason)
- *   FAST_FOUND  once the kept set is 10 % faster than the slowest one seen, i.e. is a fast one;
- *   BOX_SLOW    once six sets have been timed and the fastest is within 4 % of the slowest: this box has no fast placement to offer
+ * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others (a candidate is compared with the kept set RE-TIMED right after it and replaces it when it is
+ * 1.5 % faster: the clock drifts by more than the modes differ over a search).  A unit's search stops (cart_placement_report::stop_reason)
+ *   FAST_FOUND  once the kept set is 7 % faster than the slowest one seen (both launches fast against both slow);
+ *   BOX_SLOW    once six sets have been timed and the slowest is within 1.5 % of the kept one: the pool has nothing else to offer
  *               (about one fresh box in ten; 64 tries bought 1.4 % on such a box) -- the best seen is kept, set-up stays under 2 s;
  *   TRIES / TIME / MEMORY  out of tries, out of the unit's time share ((0.25 s per allowed try + 1 s per 20 GB of workspace) / units),
  *               or no room for another candidate.
@@ -385,7 +386,9 @@ int cart_debug_ccl_scratch_nonzero(cart_engine *engine, size_t *nonzero);
 
 /* Per-stage device time (hipEvents recorded on the caller's stream around each stage of
  * cart_compute_disparity[_batch]).  set_timing(1) enables recording and clears the record ring
- * (the last 256 calls are kept); collect_timing() synchronises the device and returns, per stage,
+ * (the last 256 recorded calls are kept); set_timing(k), k > 1, records every k-th call only (the events
+ * cost ~0.02 ms of a call's stream time: a throughput measurement that wants live stage times but not
+ * their cost on every step samples); set_timing(0) stops.  collect_timing() synchronises the device and returns, per stage,
  * the MEAN milliseconds per call over the recorded calls (names are static strings).  Returns the
  * number of stages written (<= cap) and the number of calls averaged in *n_calls. */
 int cart_engine_set_timing(cart_engine *engine, int enabled);

@@ -1,0 +1,12 @@
+#!/bin/bash
+# GPU box, round 5: does the WTA launch lose its slow placement mode when the frame is the fastest block index?  six alternating rounds, placement search OFF
+# (one try: every process keeps the placement its engine was created with, so the runs sample the modes)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_wtaz; mkdir -p $O; cd $R
+for v in wtaz wtazx; do
+  CART_ENGINE_LIB=$R/cart-slam_amd/build/ab/$v/libcart_engine.so timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -k "launch_plans_agree or xcd_placed or randomized_configurations or full_size_against_oracle or stage_by_stage" > $O/parity_$v.log 2>&1 && echo "$v parity: $(tail -1 $O/parity_$v.log)" | tee -a $O/summary.txt || { echo "$v PARITY FAILED"; tail -15 $O/parity_$v.log; exit 8; }
+done
+for r in 1 2 3 4 5 6; do for v in base wtaz wtazx; do
+  L=$R/cart-slam_amd/build/ab/$v/libcart_engine.so; [ $v = base ] && L=$R/cart-slam_amd/build/libcart_engine.so
+  CART_ENGINE_LIB=$L timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-pcie --no-bgr --steps 20 --repeats 3 --placement-tries 1 > $O/${v}_$r.json 2> $O/${v}_$r.err || { tail -3 $O/${v}_$r.err; exit 1; }
+  python3 -c 'import json,sys; d=json.loads(open(sys.argv[1]).read()); s=d["stages_ms_per_launch"]; print("%-6s %8.1f pairs/s  agg %.4f  wta %.4f" % (sys.argv[2], d["value"], s["aggregate"], s["wta"]))' $O/${v}_$r.json $v | tee -a $O/summary.txt
+done; done

@@ -83,6 +83,15 @@ def build(name):
     elif name == "g4nox":
         src = order_variant(src, 4)
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
+    elif name in ("wtaz", "wtazx"):
+        # WTA launch with the FRAME as the fastest-varying block index (wtaz: [row][tile][frame]; wtazx: [row][frame][tile]): the resident blocks then read
+        # from all 16 slots at once instead of sweeping one slot after the other -- does the launch's slow placement mode go away when its reads are spread?
+        if name == "wtaz":
+            src = sub(src, "    const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;", "    const int x0 = blockIdx.y * kWtaTileX, y = blockIdx.z, frame = blockIdx.x;")
+            src = sub(src, "    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);", "    dim3 grid(n_frames, (g.w + kWtaTileX - 1) / kWtaTileX, g.h), block(256);")
+        else:
+            src = sub(src, "    const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;", "    const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.z, frame = blockIdx.y;")
+            src = sub(src, "    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);", "    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, n_frames, g.h), block(256);")
     elif name == "nox":
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
     elif name in ("privcen", "privcen0"):
