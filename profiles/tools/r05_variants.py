@@ -92,6 +92,21 @@ def build(name):
         else:
             src = sub(src, "    const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.y, frame = blockIdx.z;", "    const int x0 = blockIdx.x * kWtaTileX, y = blockIdx.z, frame = blockIdx.y;")
             src = sub(src, "    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, g.h, n_frames), block(256);", "    dim3 grid((g.w + kWtaTileX - 1) / kWtaTileX, n_frames, g.h), block(256);")
+    elif name in ("vd4", "w8", "w2", "ntoff", "prio0", "lb7", "lb5", "hspf4", "hspf16"):
+        # the aggregation launch's tuning knobs once more, now that the launch is measured in its FAST placement mode (rounds 2-3 tuned them on workspaces above
+        # 8 GiB, i.e. in the slow mode, where the fabric's write stalls bind and the knobs could not show)
+        if name == "vd4":
+            src = sub(src, "template <int LPP> constexpr int v_depth() { return LPP == 4 ? 4 : 2; }", "template <int LPP> constexpr int v_depth() { return 4; }")
+        elif name in ("w8", "w2"):
+            src = sub(src, "constexpr int kAggWaves = 4;", "constexpr int kAggWaves = %d;" % (8 if name == "w8" else 2))
+        elif name == "ntoff":
+            src = sub(src, "        __builtin_nontemporal_store(q, (CART_GLOBAL v4u *)po);", "        *(CART_GLOBAL v4u *)po = q;")
+        elif name == "prio0":
+            src = sub(src, "        __builtin_amdgcn_s_setprio(3);\n        if constexpr (HS) {", "        if constexpr (HS) {")
+        elif name in ("lb7", "lb5"):
+            src = sub(src, "(LPP >= 8 && !HS) ? 6 : 4) void aggregate_kernel", "(LPP >= 8 && !HS) ? %s : 4) void aggregate_kernel" % name[2])
+        else:
+            src = sub(src, "constexpr int HS_PF = 8;", "constexpr int HS_PF = %s;" % name[4:])
     elif name == "nox":
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
     elif name in ("privcen", "privcen0"):
