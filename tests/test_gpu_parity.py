@@ -938,7 +938,8 @@ def test_ccl_table_in_one_call(torch_cuda):
     every call -- also after a truncated table and after an id map that is not one (foreign ids are ignored, not accumulated for ever)."""
     torch = torch_cuda
     rng = np.random.default_rng(515)
-    for w, h in [(64, 32), (65, 33), (200, 100), (16, 8), (320, 37), (70, 160), (1242, 375)]:
+    # (the last three: more than 64 tile columns per row -- the table kernel walks a row's segment counts in chunks of 64 --, a single tile column, a prime width)
+    for w, h in [(64, 32), (65, 33), (200, 100), (16, 8), (320, 37), (70, 160), (1242, 375), (16384, 8), (4160, 40), (16, 2000), (4099, 11)]:
         eng = make_engine(w, h, 0, 0, inflight=6)
         yy, xx = np.mgrid[0:h, 0:w]
         maps = [rng.integers(0, 3, (h, w)).astype(np.uint8), ((xx + yy) % 2).astype(np.uint8), np.zeros((h, w), np.uint8)]
