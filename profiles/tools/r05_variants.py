@@ -107,6 +107,15 @@ def build(name):
             src = sub(src, "(LPP >= 8 && !HS) ? 6 : 4) void aggregate_kernel", "(LPP >= 8 && !HS) ? %s : 4) void aggregate_kernel" % name[2])
         else:
             src = sub(src, "constexpr int HS_PF = 8;", "constexpr int HS_PF = %s;" % name[4:])
+    elif name in ("uc", "fg"):
+        # the slab groups from hipExtMallocWithFlags: uc = hipDeviceMallocUncached, fg = hipDeviceMallocFinegrained -- does another kind of device memory
+        # show the two placement modes?  (engine patch only; the kernels are the product's)
+        eng = open(os.path.join(PKG, "csrc", "cart_engine.hip")).read()
+        flag = "hipDeviceMallocUncached" if name == "uc" else "hipDeviceMallocFinegrained"
+        eng = sub(eng, "        if (dev_alloc(&b, sp.bytes_of(gi))) { slab_pool_free(sp); return -1; }",
+                  "        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&b), sp.bytes_of(gi), %s) != hipSuccess) { slab_pool_free(sp); return fail(\"slab alloc\"); }" % flag)
+        eng = sub(eng, "                if (dev_alloc(&cand[(size_t)gi], sp.bytes_of(gi))) { ok = false; break; }",
+                  "                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&cand[(size_t)gi]), sp.bytes_of(gi), %s) != hipSuccess) { ok = false; break; }" % flag)
     elif name == "nox":
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
     elif name in ("privcen", "privcen0"):
