@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void ccl_border_kernel(const uint8_t *planes, 
 // table row and ZEROES the entry again.  The scratch ([slot][npx] x 5 ints, zero-neutral encoding: area, w - x0, h - y0, x1 + 1,
 // y1 + 1, every field grown by atomicAdd / atomicMax from 0) is therefore all zeros between calls: no memset, no initialised table.
 constexpr int kCclStatInts = 5;
-constexpr int kCclHash = 512;
+constexpr int kCclHash = 256;   // entries of a tile's component hash (a tile with more components than fit adds their pieces to the scratch directly)
 struct CclHash { int key[kCclHash], area[kCclHash], x0[kCclHash], y0[kCclHash], x1[kCclHash], y1[kCclHash]; };
 
 __device__ __forceinline__ void ccl_hash_clear(CclHash &hsh, int tid, int w, int h) {
@@ -610,7 +610,7 @@ __device__ __forceinline__ void ccl_row_stats(CclHash &hsh, int32_t *stat, int32
     const unsigned long long stop = (heads | ~ins) & later;   // next head or first non-member lane
     const int end_lane = stop ? __ffsll((long long)stop) - 2 : 63;
     const int len = end_lane - lane + 1;
-    int hpos = (int)(((unsigned)id * 2654435761u) >> 23);   // 9 bits
+    int hpos = (int)(((unsigned)id * 2654435761u) >> 24);   // 8 bits
     for (int probe = 0; probe < 8; ++probe, hpos = (hpos + 1) & (kCclHash - 1)) {
         const int old = atomicCAS(&hsh.key[hpos], -1, id);
         if (old == -1 || old == id) {
@@ -636,8 +636,7 @@ __device__ __forceinline__ void ccl_hash_flush(const CclHash &hsh, int32_t *stat
 template <bool STATS>
 __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int32_t *ids, size_t istep, size_t ifs, int32_t *ncomp, int32_t *stat_all,
                                                         int32_t *seg_all, int w, int h, size_t npx) {
-    __shared__ int link[CT_TH * CT_TW];      // local index of the pixel's link target, -1 unlabelled, -2 resolved in root_of
-    __shared__ int root_of[CT_TH * CT_TW];
+    __shared__ int link[CT_TH * CT_TW];      // >= 0: local index of the pixel's link target; -1: unlabelled; <= -2: resolved, global root = -(value + 2)
     __shared__ int roots;
     __shared__ typename std::conditional<STATS, CclHash, int>::type hsh_mem;   // the tile's component hash exists only with STATS
     CclHash &hsh = reinterpret_cast<CclHash &>(hsh_mem);
@@ -650,7 +649,7 @@ __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int
 #pragma unroll
     for (int k = 0; k < CT_TH / 4; ++k) {
         const int r = wid * (CT_TH / 4) + k, y = y0 + r, li = r * CT_TW + lane;
-        int lk = -1, ro = -1;
+        int lk = -1;
         if (x < w && y < h) {
             const int gi = y * w + x;
             const int t = L[gi];
@@ -662,11 +661,11 @@ __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int
                 } else {   // a tile root: resolve it in the global forest
                     int q = t, n = L[q];
                     while (n != q) { q = n; n = L[q]; }
-                    lk = -2; ro = q;
+                    lk = -(q + 2);
                 }
             }
         }
-        link[li] = lk; root_of[li] = ro;
+        link[li] = lk;
     }
     __syncthreads();
     int found = 0;
@@ -677,10 +676,10 @@ __global__ __launch_bounds__(256) void ccl_final_kernel(const int32_t *work, int
         if (y >= h) continue;
         int id = -1;
         if (x < w) {
-            int cur = li, lk = link[li];
+            int lk = link[li];
             if (lk != -1) {
-                while (lk >= 0) { cur = lk; lk = link[cur]; }   // in-tile links only ever lead to smaller indices: terminates at a resolved entry
-                id = root_of[cur];
+                while (lk >= 0) lk = link[lk];   // in-tile links only ever lead to smaller indices: terminates at a resolved entry
+                id = -(lk + 2);
             }
             row_ptr(ids, ifs, istep, frame, y)[x] = id;
             found += id == y * w + x;
@@ -739,15 +738,29 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
     const int y0 = band * CT_TH, rows = min(CT_TH, h - y0);
     const int32_t *seg = seg_all + (size_t)frame * h * ntx;
     int before = 0;
-    for (int i = tid; i < y0 * ntx; i += 256) before += seg[i];
+    {   // roots in the bands above: up to a few thousand counts per block, eight independent loads in flight per thread (one load per trip ran the last band's
+        // block at 28 dependent memory latencies: 18 of the kernel's 18 us)
+        const int nb = y0 * ntx;
+        int i = tid, part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (; i + 7 * 256 < nb; i += 8 * 256) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += seg[i + u * 256];
+        }
+        for (; i < nb; i += 256) before += seg[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) before += part[u];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
     if (lane == 0) red[wid] = before;
-    if (tid < CT_TH) {
-        int s = 0;
-        if (tid < rows)
-            for (int t = 0; t < ntx; ++t) s += seg[(size_t)(y0 + tid) * ntx + t];
-        rowbase[tid + 1] = s;
+    // roots per row of the band: eight lanes per row, each a strided share of the row's segment counts (all loads of the block in flight together)
+    {
+        const int r = tid >> 3, part = tid & 7;
+        int sum = 0;
+        if (r < rows)
+            for (int t = part; t < ntx; t += 8) sum += seg[(size_t)(y0 + r) * ntx + t];
+        sum += __shfl_down(sum, 4, 8); sum += __shfl_down(sum, 2, 8); sum += __shfl_down(sum, 1, 8);
+        if (part == 0) rowbase[r + 1] = sum;
     }
     __syncthreads();
     if (tid == 0) {
