@@ -41,7 +41,8 @@ def test_single_gpu_line_is_verified_and_complete():
     assert d["bgr_input"]["disparity_equals_gray_run"] is True and d["value_bgr_input"] > 0   # the 8UC3 input disparity.cu:66-67 is handed
     assert d["value_without_stage_events"] > 0   # informational block after the timed ones, the engine's stage events off
     pt = d["placement_tuning"]
-    assert 0 < pt["launch_pair_ms_kept"] <= pt["launch_pair_ms_first"] <= pt["launch_pair_ms_slowest_seen"]
+    # (the kept set is re-timed after every candidate: its last timing may lie a per cent above the first one)
+    assert 0 < pt["launch_pair_ms_kept"] <= 1.05 * pt["launch_pair_ms_first"] and pt["launch_pair_ms_kept"] <= pt["launch_pair_ms_slowest_seen"]
     assert 1 <= pt["candidates_timed"] <= pt["units"] * pt["tries_allowed"] and pt["tries_allowed"] <= 8   # the default search is short
     assert pt["mode"] in ("fast", "slow", "box-slow") and pt["stopped_on"] in ("fast set found", "box-slow", "tries", "time", "memory")
     # the line says which mode the run ended in (unit 0's verdict; the line's times are means over the units: compare loosely)
