@@ -931,6 +931,30 @@ def test_ccl_tile_borders(torch_cuda):
 
 
 @pytest.mark.gpu
+def test_stage_timing_records_every_kth_call(torch_cuda):
+    """cart_engine_set_timing(k): HIP events around the stages of every k-th compute call only (bench.py samples its timed steps so that the
+    events' cost is not on every step); collect_timing averages what was recorded; the results never depend on it."""
+    torch = torch_cuda
+    w, h, D, P = 200, 64, 64, 8
+    ls, rs = synth.make_batch(2, w, h, D, 4, seed=3)
+    eng = make_engine(w, h, D, P, 4, radius=2, iters=1, inflight=2)
+    L, R = dev(torch, ls), dev(torch, rs)
+    ref = eng.compute_disparity(L, R).cpu().numpy()
+    for every, calls, want in ((1, 6, 6), (4, 10, 3), (3, 3, 1)):
+        eng.set_timing(True, every=every)
+        for _ in range(calls):
+            got = eng.compute_disparity(L, R)
+        stages, n = eng.collect_timing()
+        assert n == want, (every, calls, n)
+        assert set(stages) == {"census", "aggregate", "wta", "post"} and all(v > 0 for v in stages.values())   # post carries the fused first interpolation pass
+        assert (got.cpu().numpy() == ref).all()
+    eng.set_timing(False)
+    eng.compute_disparity(L, R)
+    assert eng.collect_timing()[1] == 0
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_ccl_table_in_one_call(torch_cuda):
     """cart_plane_ccl_table: ids, count and component table from ONE call (the pass that writes the final ids feeds a statistics scratch keyed
     by root pixel; ccl_table_kernel ranks the roots from per-segment counts and empties the scratch again).  Against the oracle on the tile-border
