@@ -283,9 +283,10 @@ def run(args, world, rank, dev_index):
                      "launch_pair_ms_first": round(rep["ms_first"], 4), "launch_pair_ms_kept": round(rep["ms_kept"], 4),
                      "launch_pair_ms_slowest_seen": round(rep["ms_slowest_seen"], 4), "seconds": round(rep["seconds"], 3),
                      "what": "cart_engine_tune_placement: aggregation + WTA launch of one batch on fresh physical placements of the slab workspace, fastest "
-                             "kept (set-up, outside every timed region).  mode: fast = the kept set is >= 5.5 % under the slowest seen (both launches in "
-                             "their fast modes); slow = the search ran out first; box-slow = six sets within 1.5 % of each other, this box has no fast "
-                             "placement (its aggregation launch then runs ~7 % longer: a slow box, not a regression)"}
+                             "kept (set-up, outside every timed region).  mode is RELATIVE to the sets the search saw: fast = the kept set is >= 5.5 % under "
+                             "the slowest seen (a set with a launch in its slow mode was met and avoided); mixed = the sets differ by 1.5-5.5 %, the fastest is "
+                             "kept; uniform = six sets within 1.5 % of each other (all fast or all slow: stages_ms_per_launch tells which -- the aggregation "
+                             "launch of the headline configuration takes ~1.45 ms in its fast mode, ~1.55 in its slow one, the WTA 1.16-1.19 / 1.22-1.27)"}
         placement["value_untuned"] = round(untuned, 2)
 
     # Untimed pre-warm, before the W warm-up steps the contract asks for: first touch of the workspaces (15 GB of slabs), code

@@ -43,8 +43,8 @@ class PlacementReport(C.Structure):
                 ("seconds", C.c_float), ("units", C.c_int), ("candidates", C.c_int), ("mode", C.c_int), ("stop_reason", C.c_int)]
 
 
-PLACE_MODES = {0: "unknown", 1: "fast", 2: "slow", 3: "box-slow"}                                       # CART_PLACE_MODE_*
-PLACE_STOPS = {0: "nothing to do", 1: "fast set found", 2: "box-slow", 3: "tries", 4: "time", 5: "memory"}   # CART_PLACE_STOP_*
+PLACE_MODES = {0: "unknown", 1: "fast", 2: "mixed", 3: "uniform"}                                       # CART_PLACE_MODE_*
+PLACE_STOPS = {0: "nothing to do", 1: "fast set found", 2: "uniform", 3: "tries", 4: "time", 5: "memory"}   # CART_PLACE_STOP_*
 
 
 class SuperpixelParams(C.Structure):

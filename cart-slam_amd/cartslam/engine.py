@@ -116,7 +116,7 @@ class Engine:
         """cart_engine_tune_placement (opt-in set-up step): time the slab-bound launches of an n_frames call on up to max_tries physical
         placements of the slot groups behind it and keep the fastest.  max_extra_bytes bounds what the call may hold beyond the
         workspace while it searches (0: two units' worth; None: no cap but 4 GiB left free).  -> (ms before, ms after), or with
-        report=True the whole cart_placement_report as a dict (mode: fast / slow / box-slow / unknown, candidates timed, why the search
+        report=True the whole cart_placement_report as a dict (mode: fast / mixed / uniform / unknown, relative to the sets the search saw; candidates timed, why the search
         stopped).  The engine must be idle."""
         r = _lib.PlacementReport()
         cap = C.c_size_t(-1).value if max_extra_bytes is None else int(max_extra_bytes)

@@ -264,9 +264,9 @@ constexpr size_t kSlabChunkBytes = ((size_t)8 << 30) - ((size_t)64 << 20);
 // scatters by 0.4 % (profiles/r05_placement.txt sections 2, 5, 6; on an idle GPU straight after engine creation the extremes lie 12-13 % apart,
 // which is where round 4's 0.87 came from).  A candidate replaces the kept set when it is 1.5 % faster (both timed back to back); the search stops at
 // the first kept set 7 % under the slowest seen (both launches fast against both slow); the kept set is called fast when it is 5.5 % under the
-// slowest seen; after kBoxSlowAfter timed placements that are all within 1.5 % of each other the pool has nothing else to offer.
-constexpr float kStopRatio = 0.930f, kFastRatio = 0.945f, kBoxSlowRatio = 0.985f, kSwitchRatio = 0.985f;
-constexpr int kBoxSlowAfter = 6;
+// slowest seen; after kUniformAfter timed placements that are all within 1.5 % of each other the pool offers one kind only.
+constexpr float kStopRatio = 0.930f, kFastRatio = 0.945f, kUniformRatio = 0.985f, kSwitchRatio = 0.985f;
+constexpr int kUniformAfter = 6;
 
 void slab_pool_free(SlabPool &sp) {
     for (uint8_t *b : sp.base)
@@ -576,8 +576,8 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
             // a kept placement 7 % under the slowest pair seen has both launches in their fast modes -- stop looking
             if (worst_rel * kStopRatio > 1.f) { stop = CART_PLACE_STOP_FAST_FOUND; break; }
             // A process in which no placement is fast (round 4's driver box: 64 candidates between 2.57 and 2.60 ms, 7.7 s of search for 1.4 %): once
-            // kBoxSlowAfter placements have been timed and the slowest is within 1.5 % of the kept one, there is nothing to find here -- stop.
-            if (seen >= kBoxSlowAfter && worst_rel * kBoxSlowRatio < 1.f) { stop = CART_PLACE_STOP_BOX_SLOW; break; }
+            // kUniformAfter placements have been timed and the slowest is within 1.5 % of the kept one, there is nothing to find here -- stop.
+            if (seen >= kUniformAfter && worst_rel * kUniformRatio < 1.f) { stop = CART_PLACE_STOP_UNIFORM; break; }
             if (seconds_since(t_unit) > unit_budget) { stop = CART_PLACE_STOP_TIME; break; }
             while (extra + unit_bytes > cap && !held.empty()) {   // make room under the cap: the oldest loser goes
                 (void)hipFree(held.front().p);
@@ -624,8 +624,8 @@ int cart_engine_tune_placement(cart_engine *e, int n_frames, int max_tries, size
         if (u == 0 && report && rc == 0) {   // the unit a caller with one call in flight lives in
             report->stop_reason = stop;
             report->mode = worst_rel * kFastRatio > 1.f ? CART_PLACE_MODE_FAST
-                         : (seen >= kBoxSlowAfter && worst_rel * kBoxSlowRatio < 1.f) ? CART_PLACE_MODE_BOX_SLOW
-                         : seen == 1 ? CART_PLACE_MODE_UNKNOWN : CART_PLACE_MODE_SLOW;
+                         : (seen >= kUniformAfter && worst_rel * kUniformRatio < 1.f) ? CART_PLACE_MODE_UNIFORM
+                         : seen == 1 ? CART_PLACE_MODE_UNKNOWN : CART_PLACE_MODE_MIXED;
             report->ms_fastest_seen = kept;
             report->ms_slowest_seen = worst;
         }

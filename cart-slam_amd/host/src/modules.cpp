@@ -94,7 +94,7 @@ EngineHandle::EngineHandle(Size, const cart_engine_params &params) {
     // cart_engine_tune_placement: the aggregation launch runs 8-9 % faster on some).  Not fatal: a failed probe leaves the first placement.
     if (params.num_disparities > 0 && placementTries() > 1) {
         cart_placement_report rep;
-        static const char *const modes[] = {"unknown", "fast", "slow", "box-slow"};
+        static const char *const modes[] = {"unknown", "fast", "mixed", "uniform"};
         if (cart_engine_tune_placement(engine, std::min(params.max_inflight, 16), placementTries(), /*max_extra_bytes: default cap*/ 0, &rep) != 0)
             std::fprintf(stderr, "[cartslam_amd] placement tuning failed (%s); keeping the first placement\n", cart_last_error(engine));
         else

@@ -108,13 +108,16 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * up to `max_tries - 1` freshly allocated sets, keeps the fastest and frees the others (a candidate is compared with the kept set RE-TIMED right after it and replaces it when it is
  * 1.5 % faster: the clock drifts by more than the modes differ over a search).  A unit's search stops (cart_placement_report::stop_reason)
  *   FAST_FOUND  once the kept set is 7 % faster than the slowest one seen (both launches fast against both slow);
- *   BOX_SLOW    once six sets have been timed and the slowest is within 1.5 % of the kept one: the pool has nothing else to offer
+ *   UNIFORM     once six sets have been timed and the slowest is within 1.5 % of the kept one: the pool offers one kind of placement only
  *               (about one fresh box in ten; 64 tries bought 1.4 % on such a box) -- the best seen is kept, set-up stays under 2 s;
  *   TRIES / TIME / MEMORY  out of tries, out of the unit's time share ((0.25 s per allowed try + 1 s per 20 GB of workspace) / units),
  *               or no room for another candidate.
- * `mode` says what unit 0 -- where a caller with one call in flight lives -- ended on: FAST (kept set at least 5.5 % under the slowest seen),
- * SLOW (the search ran out on a set that is not), BOX_SLOW, or UNKNOWN (one try: nothing to compare with).  The ratios hold for a probe on a
- * warmed-up GPU (call it after a few real calls, as bench.py does; straight after engine creation the levels lie 12-13 % apart).  A reader of a bench line can so tell a slow box from a regression.
+ * `mode` says what unit 0 -- where a caller with one call in flight lives -- ended on, RELATIVE to what the search saw (the engine knows no absolute
+ * level): FAST = the kept set is at least 5.5 % under the slowest seen, i.e. a set with a launch in its slow mode was met and avoided; MIXED = the sets
+ * seen differ by 1.5-5.5 % and the fastest is kept (no both-slow set was met to compare with: the kept one may well have both launches fast); UNIFORM =
+ * six sets within 1.5 % of each other (all fast or all slow: the stage times tell which -- at 1242x375 D=128 P=8 the aggregation launch takes ~1.45 ms in
+ * its fast mode and ~1.55 in its slow one); UNKNOWN = one try, nothing to compare with.  The ratios hold for a probe on a warmed-up GPU (call it after
+ * a few real calls, as bench.py does; straight after engine creation the levels lie 12-13 % apart).
  * TRANSIENT FOOTPRINT: candidates that lost stay allocated while the search goes on (freed at once, the allocator would hand the same
  * pages back); at no time does the call hold more than `max_extra_bytes` beyond the engine's own workspace -- 0 selects two units' worth
  * (one unit = the groups of one n-frame call: 7.6 GB at 1242x375 D=128 P=8 with n = 16), SIZE_MAX lifts the cap (the search then stops
@@ -122,8 +125,8 @@ int cart_engine_describe_plan(cart_engine *engine, int n_frames, cart_launch_pla
  * several processes share a GPU).  With a cap below one unit the call measures and returns without trying anything.  Peak device memory
  * of the process during the call = workspace + min(max_extra_bytes, (max_tries - 1) x unit); after it, the workspace alone.
  * The engine must be idle; results do not change (every placement gives the same bits).  `report` may be NULL. */
-enum { CART_PLACE_MODE_UNKNOWN = 0, CART_PLACE_MODE_FAST = 1, CART_PLACE_MODE_SLOW = 2, CART_PLACE_MODE_BOX_SLOW = 3 };
-enum { CART_PLACE_STOP_NOTHING_TO_DO = 0, CART_PLACE_STOP_FAST_FOUND = 1, CART_PLACE_STOP_BOX_SLOW = 2, CART_PLACE_STOP_TRIES = 3,
+enum { CART_PLACE_MODE_UNKNOWN = 0, CART_PLACE_MODE_FAST = 1, CART_PLACE_MODE_MIXED = 2, CART_PLACE_MODE_UNIFORM = 3 };
+enum { CART_PLACE_STOP_NOTHING_TO_DO = 0, CART_PLACE_STOP_FAST_FOUND = 1, CART_PLACE_STOP_UNIFORM = 2, CART_PLACE_STOP_TRIES = 3,
        CART_PLACE_STOP_TIME = 4, CART_PLACE_STOP_MEMORY = 5 };
 typedef struct {
     float ms_first, ms_kept;                 /* launch-pair time (aggregation + WTA of n frames), mean over the probed units, before / after */

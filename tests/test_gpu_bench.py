@@ -44,7 +44,7 @@ def test_single_gpu_line_is_verified_and_complete():
     # (the kept set is re-timed after every candidate: its last timing may lie a per cent above the first one)
     assert 0 < pt["launch_pair_ms_kept"] <= 1.05 * pt["launch_pair_ms_first"] and pt["launch_pair_ms_kept"] <= pt["launch_pair_ms_slowest_seen"]
     assert 1 <= pt["candidates_timed"] <= pt["units"] * pt["tries_allowed"] and pt["tries_allowed"] <= 8   # the default search is short
-    assert pt["mode"] in ("fast", "slow", "box-slow") and pt["stopped_on"] in ("fast set found", "box-slow", "tries", "time", "memory")
+    assert pt["mode"] in ("fast", "mixed", "uniform") and pt["stopped_on"] in ("fast set found", "uniform", "tries", "time", "memory")
     # the line says which mode the run ended in (unit 0's verdict; the line's times are means over the units: compare loosely)
     assert pt["mode"] != "fast" or pt["launch_pair_ms_kept"] < 0.97 * pt["launch_pair_ms_slowest_seen"]
     assert pt["value_untuned"] > 0 and pt["seconds"] < 12
