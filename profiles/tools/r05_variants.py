@@ -116,6 +116,14 @@ def build(name):
                   "        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&b), sp.bytes_of(gi), %s) != hipSuccess) { slab_pool_free(sp); return fail(\"slab alloc\"); }" % flag)
         eng = sub(eng, "                if (dev_alloc(&cand[(size_t)gi], sp.bytes_of(gi))) { ok = false; break; }",
                   "                if (hipExtMallocWithFlags(reinterpret_cast<void **>(&cand[(size_t)gi]), sp.bytes_of(gi), %s) != hipSuccess) { ok = false; break; }" % flag)
+    elif name in ("fs_noagg", "fs_nocensus"):
+        # timing builds of the fused sweep (results wrong by design): fs_noagg = no "up" recurrence at all (slab loads + sums + WTA only: what the sweep's
+        # memory access alone costs), fs_nocensus = recurrence on constant features (no census loads / LDS window staging)
+        if name == "fs_noagg":
+            src = sub(src, "        agg_step<LPP, false>(st, mm, xr, sel_lo, sel_hi, p1p1, p2p2, nullptr);\n    };", "        (void)xr;\n    };")
+        else:
+            src = sub(src, "        win_read<LPP>(wbuf, rbase, c.r);\n        uint32_t xr[16];\n        agg_xor(c, xr);\n        load_census_row(max(y - 1, 0));",
+                      "        uint32_t xr[16];\n#pragma unroll\n        for (int k = 0; k < 16; ++k) xr[k] = (uint32_t)(k * 0x01010101) ^ (uint32_t)y;")
     elif name == "nox":
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
     elif name in ("privcen", "privcen0"):
