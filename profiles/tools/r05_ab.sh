@@ -21,6 +21,9 @@ CFG[ref]="--disparities 256 --paths 4"
 CFG[c3]="--width 1920 --height 1080 --disparities 256 --paths 8 --batch 4"
 CFG[c3p4]="--width 1920 --height 1080 --disparities 256 --paths 4 --batch 4"
 CFG[c2b8]="--batch 8"
+CFG[d128p4f]="--disparities 128 --paths 4 --plan fused_up"
+CFG[d64p4f]="--disparities 64 --paths 4 --plan fused_up"
+CFG[ref8]="--disparities 256 --paths 4 --batch 8"
 CFG[c2b32]="--batch 32 --chunk 32"
 for r in $(seq $ROUNDS); do
   for c in ${CONFIGS:-c2}; do

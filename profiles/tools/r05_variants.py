@@ -124,6 +124,9 @@ def build(name):
         else:
             src = sub(src, "        win_read<LPP>(wbuf, rbase, c.r);\n        uint32_t xr[16];\n        agg_xor(c, xr);\n        load_census_row(max(y - 1, 0));",
                       "        uint32_t xr[16];\n#pragma unroll\n        for (int k = 0; k < 16; ++k) xr[k] = (uint32_t)(k * 0x01010101) ^ (uint32_t)y;")
+    elif name == "ns2":
+        # the fused sweep with two slab rows in flight for every variant (the product until the 4-path sweeps got four)
+        src = sub(src, "template <int NP> constexpr int fused_rows_in_flight() { return NP <= 4 ? 4 : 2; }", "template <int NP> constexpr int fused_rows_in_flight() { return 2; }")
     elif name == "nox":
         src = sub(src, "    return n_frames > 0 && (n_frames & 7) == 0 && g.census_elems * 8 <= (size_t)(8u << 20);", "    return false;")
     elif name in ("privcen", "privcen0"):
