@@ -729,10 +729,12 @@ __global__ __launch_bounds__(256) void ccl_stats_tile_kernel(const int32_t *ids,
 // (a tile row) and frame: roots before the band and per row of the band from seg[][] (a few thousand ints per frame), then each wave walks its
 // rows segment by segment, opens the segments that hold a root, ranks the roots by ballot, writes their table rows from the scratch entries and
 // zeroes those.  The band that ends the image writes the frame's component count.
-__global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs,
+constexpr int kTableWaves = 16;   // waves per band of 32 rows: a row's root-bearing segments are walked one after the other by ONE wave, so the rows go to as many waves as a workgroup holds
+__global__ __launch_bounds__(64 * kTableWaves) void ccl_table_kernel(const uint8_t *planes, size_t pstep, size_t pfs, const int32_t *ids, size_t istep, size_t ifs,
                                                         int32_t *stat_all, const int32_t *seg_all, cart_component *table, int max_components,
                                                         int32_t *ncomp, int w, int h, int ntx, size_t npx) {
-    __shared__ int red[4];
+    constexpr int NT = 64 * kTableWaves;
+    __shared__ int red[kTableWaves];
     __shared__ int rowbase[CT_TH + 1];
     const int band = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int y0 = band * CT_TH, rows = min(CT_TH, h - y0);
@@ -742,11 +744,11 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
         // block at 28 dependent memory latencies: 18 of the kernel's 18 us)
         const int nb = y0 * ntx;
         int i = tid, part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (; i + 7 * 256 < nb; i += 8 * 256) {
+        for (; i + 7 * NT < nb; i += 8 * NT) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) part[u] += seg[i + u * 256];
+            for (int u = 0; u < 8; ++u) part[u] += seg[i + u * NT];
         }
-        for (; i < nb; i += 256) before += seg[i];
+        for (; i < nb; i += NT) before += seg[i];
 #pragma unroll
         for (int u = 0; u < 8; ++u) before += part[u];
     }
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
     for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
     if (lane == 0) red[wid] = before;
     // roots per row of the band: eight lanes per row, each a strided share of the row's segment counts (all loads of the block in flight together)
-    {
+    if (tid < 8 * CT_TH) {
         const int r = tid >> 3, part = tid & 7;
         int sum = 0;
         if (r < rows)
@@ -764,7 +766,8 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
     }
     __syncthreads();
     if (tid == 0) {
-        int run = red[0] + red[1] + red[2] + red[3];
+        int run = 0;
+        for (int k = 0; k < kTableWaves; ++k) run += red[k];
         rowbase[0] = run;
         for (int r = 0; r < CT_TH; ++r) { run += rowbase[r + 1]; rowbase[r + 1] = run; }   // rowbase[r] = roots before row y0 + r
         if (ncomp && y0 + rows >= h) ncomp[frame] = run;
@@ -772,19 +775,20 @@ __global__ __launch_bounds__(256) void ccl_table_kernel(const uint8_t *planes, s
     __syncthreads();
     int32_t *stat = stat_all + (size_t)frame * npx * kCclStatInts;
     cart_component *tab = table + (size_t)frame * max_components;
-    // A wave takes rows wid, wid + 4, ...: lane t holds the count of segment c0 + t (all of a row's counts in ONE load; the rows' loads are independent
+    // A wave takes rows wid, wid + kTableWaves, ...: lane t holds the count of segment c0 + t (all of a row's counts in ONE load; the rows' loads are independent
     // and in flight together), the segments that hold a root are then walked from a ballot -- a typical label map has a few hundred roots per frame, so most
     // rows open no segment at all.
     for (int c0 = 0; c0 < ntx; c0 += 64) {
-        int cnt[CT_TH / 4];
+        static_assert(CT_TH % kTableWaves == 0, "rows of a band are dealt evenly over the waves");
+        int cnt[CT_TH / kTableWaves];
 #pragma unroll
-        for (int k = 0; k < CT_TH / 4; ++k) {
-            const int r = wid + 4 * k;
+        for (int k = 0; k < CT_TH / kTableWaves; ++k) {
+            const int r = wid + kTableWaves * k;
             cnt[k] = (r < rows && c0 + lane < ntx) ? seg[(size_t)(y0 + r) * ntx + c0 + lane] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < CT_TH / 4; ++k) {
-            const int r = wid + 4 * k;
+        for (int k = 0; k < CT_TH / kTableWaves; ++k) {
+            const int r = wid + kTableWaves * k;
             if (r >= rows) continue;   // wave-uniform
             const int y = y0 + r;
             unsigned long long todo = __ballot(cnt[k] > 0);
@@ -837,7 +841,7 @@ void launch_ccl(const uint8_t *planes, size_t pstep, size_t pfs, int32_t *work, 
     }
     if (table) {
         hipLaunchKernelGGL(ccl_final_kernel<true>, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, (int32_t *)nullptr, stat, seg, w, h, npx);
-        hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, (const int32_t *)ids, istep, ifs, stat, (const int32_t *)seg, table,
+        hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(64 * kTableWaves), 0, s, planes, pstep, pfs, (const int32_t *)ids, istep, ifs, stat, (const int32_t *)seg, table,
                            max_components, ncomp, w, h, ntx, npx);
     } else {
         hipLaunchKernelGGL(ccl_final_kernel<false>, dim3(ntx, nty, n_frames), dim3(256), 0, s, (const int32_t *)work, ids, istep, ifs, ncomp, (int32_t *)nullptr,
@@ -851,7 +855,7 @@ void launch_ccl_stats(const uint8_t *planes, size_t pstep, size_t pfs, const int
     const size_t npx = (size_t)w * h;
     const int ntx = (w + CT_TW - 1) / CT_TW, nty = (h + CT_TH - 1) / CT_TH;
     hipLaunchKernelGGL(ccl_stats_tile_kernel, dim3(ntx, nty, n_frames), dim3(256), 0, s, ids, istep, ifs, stat, seg, w, h, npx);
-    hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(256), 0, s, planes, pstep, pfs, ids, istep, ifs, stat, (const int32_t *)seg, table, max_components,
+    hipLaunchKernelGGL(ccl_table_kernel, dim3(nty, n_frames), dim3(64 * kTableWaves), 0, s, planes, pstep, pfs, ids, istep, ifs, stat, (const int32_t *)seg, table, max_components,
                        ncomp, w, h, ntx, npx);
 }
 size_t ccl_stats_ws_ints(int w, int h) { return (size_t)w * h * kCclStatInts + (size_t)h * ((w + CT_TW - 1) / CT_TW); }
