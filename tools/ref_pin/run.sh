@@ -10,6 +10,7 @@
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd); PREFIX=${1:-}
 if [ -n "$PREFIX" ]; then export PKG_CONFIG_PATH="$PREFIX/lib/pkgconfig:$PREFIX/lib64/pkgconfig:${PKG_CONFIG_PATH:-}"; export LD_LIBRARY_PATH="$PREFIX/lib:$PREFIX/lib64:${LD_LIBRARY_PATH:-}"; fi
+command -v pkg-config > /dev/null || { echo "run.sh: pkg-config not found (it locates the OpenCV the reference itself links)" >&2; exit 1; }
 if ! pkg-config --exists opencv4; then echo "run.sh: no opencv4.pc found (give the install prefix of an OpenCV built with -DOPENCV_GENERATE_PKGCONFIG=ON)" >&2; exit 1; fi
 if ! pkg-config --libs opencv4 | tr ' ' '\n' | grep -q cudastereo; then echo "run.sh: this OpenCV ($(pkg-config --modversion opencv4)) has no cudastereo module: it needs WITH_CUDA + opencv_contrib (README.md)" >&2; exit 1; fi
 python3 "$HERE/export_inputs.py" "$HERE/inputs"
